@@ -1,0 +1,158 @@
+/* rtmi.h -- C ABI of the MI355X trace-loop library (librtmi.so).
+ *
+ * This is the drop-in boundary for the per-pixel trace loop of Li-Yeun/Raytracer.  In the reference
+ * the host (`Renderer::Init()/Tick()`, renderer.cpp:6-70, 446-643; `Scene::Scene()`, template/scene.h:94-217)
+ * talks to the device only through the OpenCL wrappers `Buffer` and `Kernel`
+ * (template/precomp.h:1351-1553).  Every entry point below names the reference interface it replaces.
+ * Plain C: opaque handle, plain pointers and sizes, caller owns every host array (the library copies
+ * during the call, like `Buffer::CopyToDevice`, template.cpp:1283-1287).  Every function returns
+ * RTMI_OK (0) or a negative rtmi_status; no exceptions, no exit() (the reference's FatalError/CHECKCL,
+ * template.cpp:1099-1190, become status codes + rtmi_last_error).
+ *
+ * One host thread per handle.  Calls are synchronous on return unless stated.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtmi_ctx rtmi_ctx;
+
+typedef enum rtmi_status {
+	RTMI_OK = 0,
+	RTMI_ERR_INVALID = -1,    /* bad argument / call order */
+	RTMI_ERR_HIP = -2,        /* a HIP runtime call failed (message in rtmi_last_error) */
+	RTMI_ERR_NO_SCENE = -3,   /* render/trace before rtmi_upload_scene */
+	RTMI_ERR_BVH = -4,        /* malformed node array (cycle, out-of-range index, depth > RTMI_MAX_BVH_DEPTH) */
+	RTMI_ERR_NOMEM = -5
+} rtmi_status;
+
+/* == Renderer::VisualizationMode, renderer.h:9 */
+typedef enum rtmi_mode { RTMI_NORMAL = 0, RTMI_DISTANCE = 1, RTMI_ALBEDO = 2, RTMI_RAYTRACING = 3, RTMI_PATHTRACING = 4 } rtmi_mode;
+
+/* == Material::MaterialType, material.h:6 */
+typedef enum rtmi_material { RTMI_DIFFUSE = 0, RTMI_MIRROR = 1, RTMI_GLASS = 2, RTMI_SUBSTANCE = 3, RTMI_LIGHT = 4 } rtmi_material;
+
+#define RTMI_MAX_BVH_DEPTH 64 /* == stack[64] of BVH::IntersectBVHStack, bvh.h:540 */
+
+/* == GPUBVHNode, bvh.h:11-16 (32 bytes).  Node 0 dummy root, node 1 = plane leaf, node 2 = primitive root,
+ * children of an interior node are leftFirst and leftFirst+1 (bvh.h:56, 380-381). */
+typedef struct rtmi_bvh_node {
+	float aabbMinx, aabbMiny, aabbMinz;
+	float aabbMaxx, aabbMaxy, aabbMaxz;
+	int32_t leftFirst, primitiveCount;
+} rtmi_bvh_node;
+
+/* Scene upload: exactly the arrays the reference marshals in Scene::Scene() (template/scene.h:94-217) and hands
+ * to its kernels in Renderer::Tick (renderer.cpp:456-510).  Global object index order: quads, spheres, cubes,
+ * planes, triangles.  `total` = sum of the five counts. */
+typedef struct rtmi_scene_desc {
+	int32_t n_quads, n_spheres, n_cubes, n_planes, n_triangles; /* renderer.cpp:457 */
+	const float* quad_inv_T;        /* [n_quads][16]  mat4 row-major, scene.h:117 */
+	const float* quad_size;         /* [n_quads]      half size, scene.h:118 */
+	const float* sphere_info;       /* [n_spheres][4] pos.xyz, r^2, scene.h:132 */
+	const float* sphere_invr;       /* [n_spheres]    scene.h:135 */
+	const float* cube_M;            /* [n_cubes][16]  scene.h:153 */
+	const float* cube_inv_M;        /* [n_cubes][16]  scene.h:148 */
+	const float* cube_b;            /* [n_cubes][2][4] scene.h:149-150 */
+	const float* tri_verts;         /* [n_triangles][3][4] pos1,pos2,pos3 (w=0), scene.h:177-179 */
+	const float* primitives;        /* [total][4] quad N | sphere centre | cube 0 | plane (N,d) | triangle N, scene.h:120-181 */
+	const float* albedo;            /* [total][4] material.color, scene.h:121-182 */
+	const int32_t* material_type;   /* [total]    rtmi_material, scene.h:116-176 */
+	const float* ior;               /* [total]    scene.h:123-184 */
+	const float* absorption;        /* [total][4] scene.h:124-185 */
+	const rtmi_bvh_node* nodes;     /* [n_nodes]  bvh->gpuBvhNode, scene.h:216 */
+	int32_t n_nodes;                /* bvh->nodesUsed */
+	const int32_t* prim_idx;        /* [n_spheres+n_triangles] bvh->primitiveIdx, scene.h:217; < n_spheres => sphere */
+	float light_corners[12];        /* quads[0].c1,c2,c3 as float4, scene.h:208 */
+	float light_A, light_s;         /* renderer.cpp:483 */
+	float light_emission[4];        /* renderer.cpp:483 */
+	const uint32_t* texture;        /* [tex_w*tex_h] logo, 0x00RRGGBB, scene.h:212-213 */
+	int32_t tex_w, tex_h;           /* 128 x 64 */
+	/* Whitted point lights, Scene::GetLightPos/GetLightColor/intensity (scene.h:343-358, 562-564) */
+	float whitted_light_pos[2][4];
+	float whitted_light_color[2][4];
+	float whitted_intensity;
+} rtmi_scene_desc;
+
+/* == the three PostProcessing passes in the order the app applies them (template.cpp:310-317):
+ * gamma -> chromatic aberration -> vignette.  A pass whose enable flag is 0 is skipped. */
+typedef struct rtmi_postfx {
+	int32_t gamma_on, chroma_on, vignette_on;
+	float gamma, chroma_intensity, vignette_intensity;
+} rtmi_postfx;
+
+typedef struct rtmi_stats {
+	uint64_t primary_samples;   /* pixel-samples started since rtmi_reset_stats */
+	uint64_t extend_rays;       /* closest-hit rays traversed */
+	uint64_t shadow_rays;       /* any-hit rays traversed */
+	/* the four below are filled only while count_nodes is on (counting instantiation of the kernels), else 0 */
+	uint64_t extend_pairs;      /* 64-byte two-child node records fetched by closest-hit traversal */
+	uint64_t extend_prims;      /* 48-byte leaf primitive records tested by closest-hit traversal */
+	uint64_t shadow_pairs;      /* same for any-hit traversal */
+	uint64_t shadow_prims;
+	uint64_t bounce_launches;   /* extend/shade/connect rounds */
+	double   ms_extend, ms_shade, ms_connect, ms_other; /* hipEvent time per kernel class (profiling mode only) */
+	uint64_t n_extend_launches, n_shade_launches, n_connect_launches;
+} rtmi_stats;
+
+/* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,
+ * template.cpp:1513-1665).  One handle = one GPU (`device_id` is the HIP ordinal). */
+int rtmi_create( rtmi_ctx** out, int device_id, int width, int height );
+int rtmi_destroy( rtmi_ctx* );
+/* Run on a caller-owned HIP stream (a torch stream's cuda_stream) instead of the handle's own.  NULL restores it. */
+int rtmi_set_stream( rtmi_ctx*, void* hip_stream );
+
+/* Replaces the first-tick SetArguments + CopyToDevice block (renderer.cpp:453-513).  The library repacks the
+ * reference-layout arrays into its own 64-byte-aligned two-child node records and leaf-ordered primitive records. */
+int rtmi_upload_scene( rtmi_ctx*, const rtmi_scene_desc* );
+/* Replaces cameraPropBuffer->CopyToDevice (renderer.cpp:24, 63, 631): 4 x float4 = camPos, topLeft, topRight,
+ * bottomLeft (camera.h:25, 125-128). */
+int rtmi_set_camera( rtmi_ctx*, const float cam[16] );
+/* Replaces seedBuffer (renderer.cpp:51-57): W*H xorshift32 outputs.  State of (pixel p, sample s) is
+ * WangHash(seeds[p] + s*0x9E3779B9) (0 -> 1), SURVEY A.5. */
+int rtmi_set_seeds( rtmi_ctx*, const uint32_t* seeds );
+/* Replaces memset(accumulator) + accumulatorBuffer->CopyToDevice (renderer.cpp:622-633, renderer.h:43-77). */
+int rtmi_reset_accumulator( rtmi_ctx* );
+/* Accumulate into a caller-owned device buffer of W*H float4 (e.g. a torch tensor that torch.distributed reduces
+ * over RCCL) instead of the handle's own accumulatorBuffer (renderer.cpp:23).  NULL restores the internal one. */
+int rtmi_set_accumulator( rtmi_ctx*, void* device_float4 );
+
+/* Replaces the per-frame kernel sequence of Renderer::Tick (renderer.cpp:522-557: GeneratePrimaryRays,
+ * InitialExtend, Shade, Connect, {Extend, Shade, Connect}*), WITHOUT Finalize.
+ *   mode RTMI_PATHTRACING: accumulator[p] += Sample(primary ray p) for sample indices
+ *        sample_begin, sample_begin+sample_stride, ... (sample_count of them)   -- renderer.cpp:246-365, 559-567
+ *   other modes: accumulator[p] = Trace(primary ray p, 0) with recursion limit max_depth (renderer.cpp:133-244,
+ *        578-592); sample_* ignored; anti_aliasing != 0 selects the 4-sample pattern of renderer.cpp:594-618.
+ * Asynchronous on the handle's stream; any read-back call synchronises. */
+int rtmi_render( rtmi_ctx*, int mode, int sample_begin, int sample_count, int sample_stride, int max_depth, int anti_aliasing );
+
+/* Parity hooks (no reference counterpart as an API; they expose Scene::FindNearest / Scene::IsOccluded,
+ * scene.h:359-379, for the primary rays of the current camera and for caller rays).  prim ids are global object
+ * indices, -1 = miss. */
+int rtmi_trace_primary( rtmi_ctx*, int32_t* prim_id_out, float* t_out );
+int rtmi_trace_rays( rtmi_ctx*, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* prim_id_out, float* t_out );
+
+/* Replaces Finalize + deviceBuffer->CopyFromDevice (renderer.cpp:553-556; RGBF32_to_RGB8, precomp.h:431-465) and,
+ * when fx != NULL, the PostProcessing passes (postprocessing.h:16-99).  frames <= 0 selects the one-argument
+ * RGBF32_to_RGB8 (Whitted path). */
+int rtmi_finalize( rtmi_ctx*, uint32_t* rgb8_out, int frames, const rtmi_postfx* fx );
+/* Post-processing alone on a caller image (PostProcessing ctor + passes, postprocessing.h:6-99). */
+int rtmi_postprocess( rtmi_ctx*, uint32_t* rgb8_inout, int width, int height, const rtmi_postfx* fx );
+/* accumulatorBuffer->CopyFromDevice equivalent: W*H*4 floats. */
+int rtmi_read_accumulator( rtmi_ctx*, float* rgba_out );
+int rtmi_synchronize( rtmi_ctx* );
+
+/* Counters and timing (the reference only prints a frame time, renderer.cpp:635-641). */
+int rtmi_set_profiling( rtmi_ctx*, int hip_event_timing, int count_nodes );
+int rtmi_get_stats( rtmi_ctx*, rtmi_stats* out );
+int rtmi_reset_stats( rtmi_ctx* );
+const char* rtmi_last_error( rtmi_ctx* );
+const char* rtmi_version( void );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

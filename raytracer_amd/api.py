@@ -1,0 +1,442 @@
+"""ctypes bindings used by the Python harness (tests/, bench.py, __graft_entry__.py).
+
+Two libraries, both built in-tree by raytracer_amd/build.py:
+  librtmi.so       the C ABI of include/rtmi.h (HIP kernels).  `Device` wraps one rtmi_ctx.
+  librtmi_host.so  the C++ host mirror of the reference API (Scene, BVH, Camera, Renderer).
+
+There is no Python or CPU implementation of the trace loop in this package: every render/trace call goes
+through librtmi.so and raises `RtmiError` if the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+ASSETS = os.path.join(ROOT, "assets")
+
+# rtmi_mode / rtmi_material (include/rtmi.h)
+NORMAL, DISTANCE, ALBEDO, RAYTRACING, PATHTRACING = range(5)
+DIFFUSE, MIRROR, GLASS, SUBSTANCE, LIGHT = range(5)
+REFERENCE_SAH, BINNED_SAH = 0, 1
+
+
+class RtmiError(RuntimeError):
+    pass
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("aabbMinx", C.c_float), ("aabbMiny", C.c_float), ("aabbMinz", C.c_float),
+                ("aabbMaxx", C.c_float), ("aabbMaxy", C.c_float), ("aabbMaxz", C.c_float),
+                ("leftFirst", C.c_int32), ("primitiveCount", C.c_int32)]
+
+
+FP = C.POINTER(C.c_float)
+IP = C.POINTER(C.c_int32)
+UP = C.POINTER(C.c_uint32)
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_quads", C.c_int32), ("n_spheres", C.c_int32), ("n_cubes", C.c_int32), ("n_planes", C.c_int32), ("n_triangles", C.c_int32),
+                ("quad_inv_T", FP), ("quad_size", FP), ("sphere_info", FP), ("sphere_invr", FP),
+                ("cube_M", FP), ("cube_inv_M", FP), ("cube_b", FP), ("tri_verts", FP),
+                ("primitives", FP), ("albedo", FP), ("material_type", IP), ("ior", FP), ("absorption", FP),
+                ("nodes", C.POINTER(BvhNode)), ("n_nodes", C.c_int32), ("prim_idx", IP),
+                ("light_corners", C.c_float * 12), ("light_A", C.c_float), ("light_s", C.c_float), ("light_emission", C.c_float * 4),
+                ("texture", UP), ("tex_w", C.c_int32), ("tex_h", C.c_int32),
+                ("whitted_light_pos", (C.c_float * 4) * 2), ("whitted_light_color", (C.c_float * 4) * 2), ("whitted_intensity", C.c_float)]
+
+    @property
+    def total(self):
+        return self.n_quads + self.n_spheres + self.n_cubes + self.n_planes + self.n_triangles
+
+    def arrays(self):
+        """numpy views (no copies) of every array, keyed by field name."""
+        def view(ptr, shape, dtype):
+            n = int(np.prod(shape))
+            if n == 0 or not ptr:
+                return np.zeros(shape, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_byte)), (n * np.dtype(dtype).itemsize,)).view(dtype).reshape(shape)
+        t, nb = self.total, self.n_spheres + self.n_triangles
+        return {
+            "quad_inv_T": view(self.quad_inv_T, (self.n_quads, 16), np.float32), "quad_size": view(self.quad_size, (self.n_quads,), np.float32),
+            "sphere_info": view(self.sphere_info, (self.n_spheres, 4), np.float32), "sphere_invr": view(self.sphere_invr, (self.n_spheres,), np.float32),
+            "cube_M": view(self.cube_M, (self.n_cubes, 16), np.float32), "cube_inv_M": view(self.cube_inv_M, (self.n_cubes, 16), np.float32),
+            "cube_b": view(self.cube_b, (self.n_cubes, 2, 4), np.float32), "tri_verts": view(self.tri_verts, (self.n_triangles, 3, 4), np.float32),
+            "primitives": view(self.primitives, (t, 4), np.float32), "albedo": view(self.albedo, (t, 4), np.float32),
+            "material_type": view(self.material_type, (t,), np.int32), "ior": view(self.ior, (t,), np.float32), "absorption": view(self.absorption, (t, 4), np.float32),
+            "nodes": view(self.nodes, (self.n_nodes, 8), np.uint32), "prim_idx": view(self.prim_idx, (nb,), np.int32),
+            "texture": view(self.texture, (self.tex_h, self.tex_w), np.uint32),
+            "light_corners": np.array(self.light_corners, np.float32).reshape(3, 4),
+            "light": np.array([self.light_A, self.light_s] + list(self.light_emission), np.float32),
+            "whitted_light_pos": np.array([list(r) for r in self.whitted_light_pos], np.float32),
+            "whitted_light_color": np.array([list(r) for r in self.whitted_light_color], np.float32),
+            "whitted_intensity": np.float32(self.whitted_intensity),
+        }
+
+
+class PostFx(C.Structure):
+    _fields_ = [("gamma_on", C.c_int32), ("chroma_on", C.c_int32), ("vignette_on", C.c_int32),
+                ("gamma", C.c_float), ("chroma_intensity", C.c_float), ("vignette_intensity", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("primary_samples", C.c_uint64), ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("extend_pairs", C.c_uint64), ("extend_prims", C.c_uint64), ("shadow_pairs", C.c_uint64), ("shadow_prims", C.c_uint64),
+                ("bounce_launches", C.c_uint64),
+                ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_connect", C.c_double), ("ms_other", C.c_double),
+                ("n_extend_launches", C.c_uint64), ("n_shade_launches", C.c_uint64), ("n_connect_launches", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int), ("color", C.c_float * 3), ("ior", C.c_float), ("absorption", C.c_float * 3), ("emission", C.c_float * 3)]
+
+    def __init__(self, type=DIFFUSE, color=(0.93, 0.93, 0.93), ior=1.0, absorption=(0, 0, 0), emission=(0, 0, 0)):
+        super().__init__(type, (C.c_float * 3)(*color), ior, (C.c_float * 3)(*absorption), (C.c_float * 3)(*emission))
+
+
+_dev = None
+_host = None
+
+
+def _ptr(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+def device_lib():
+    """librtmi.so; raises RtmiError if it was not built."""
+    global _dev
+    if _dev is None:
+        path = os.path.join(_PKG, "librtmi.so")
+        if not os.path.exists(path):
+            raise RtmiError("librtmi.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)")
+        L = C.CDLL(path)
+        L.rtmi_last_error.restype = C.c_char_p
+        L.rtmi_version.restype = C.c_char_p
+        for name in ("rtmi_create", "rtmi_destroy", "rtmi_set_stream", "rtmi_upload_scene", "rtmi_set_camera", "rtmi_set_seeds", "rtmi_reset_accumulator",
+                     "rtmi_set_accumulator", "rtmi_render", "rtmi_trace_primary", "rtmi_trace_rays", "rtmi_finalize", "rtmi_postprocess",
+                     "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats"):
+            getattr(L, name).restype = C.c_int
+        L.rtmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+        L.rtmi_destroy.argtypes = [C.c_void_p]
+        L.rtmi_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.rtmi_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.rtmi_set_camera.argtypes = [C.c_void_p, C.c_void_p]
+        L.rtmi_set_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        L.rtmi_reset_accumulator.argtypes = [C.c_void_p]
+        L.rtmi_set_accumulator.argtypes = [C.c_void_p, C.c_void_p]
+        L.rtmi_render.argtypes = [C.c_void_p] + [C.c_int] * 6
+        L.rtmi_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtmi_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rtmi_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(PostFx)]
+        L.rtmi_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(PostFx)]
+        L.rtmi_read_accumulator.argtypes = [C.c_void_p, C.c_void_p]
+        L.rtmi_synchronize.argtypes = [C.c_void_p]
+        L.rtmi_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rtmi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rtmi_reset_stats.argtypes = [C.c_void_p]
+        L.rtmi_last_error.argtypes = [C.c_void_p]
+        _dev = L
+    return _dev
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = os.path.join(_PKG, "librtmi_host.so")
+        if not os.path.exists(path):
+            raise RtmiError("librtmi_host.so is missing: run __graft_entry__.build()")
+        device_lib()  # librtmi_host.so links librtmi.so
+        L = C.CDLL(path)
+        L.rth_scene_create.restype = C.c_void_p
+        L.rth_scene_destroy.argtypes = [C.c_void_p]
+        L.rth_scene_make_default.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.rth_scene_make_room.argtypes = [C.c_void_p]
+        L.rth_scene_add_sphere.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
+        L.rth_scene_add_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(Material), C.c_float, C.c_float, C.c_float]
+        L.rth_scene_add_torus_knot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
+        L.rth_scene_load_obj.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Material), C.c_float, C.c_float, C.c_float]
+        L.rth_scene_load_texture_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.rth_scene_finalize.argtypes = [C.c_void_p, C.c_int]
+        L.rth_scene_desc.argtypes = [C.c_void_p]
+        L.rth_scene_desc.restype = C.POINTER(SceneDesc)
+        L.rth_scene_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.rth_quad_T.argtypes = [C.c_void_p, C.c_void_p]
+        L.rth_fill_seeds.argtypes = [C.c_void_p, C.c_longlong]
+        L.rth_camera_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.rth_camera_primary_rays.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rth_bvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rth_triangle_derived.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rth_torus_knot.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.rth_torus_knot.restype = C.c_longlong
+        L.rth_write_obj.argtypes = [C.c_char_p, C.c_void_p, C.c_longlong]
+        L.rth_renderer_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.rth_renderer_create.restype = C.c_void_p
+        for n in ("rth_renderer_destroy", "rth_renderer_init", "rth_renderer_upload_scene"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.rth_renderer_scene.argtypes = [C.c_void_p]
+        L.rth_renderer_scene.restype = C.c_void_p
+        L.rth_renderer_tick.argtypes = [C.c_void_p, C.c_float]
+        for n in ("rth_renderer_set_mode", "rth_renderer_set_aa", "rth_renderer_set_depth", "rth_renderer_set_spp_per_tick"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
+        L.rth_renderer_set_postfx.argtypes = [C.c_void_p, C.POINTER(PostFx), C.c_int]
+        L.rth_renderer_key.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rth_renderer_frames.argtypes = [C.c_void_p]
+        L.rth_renderer_frames.restype = C.c_uint
+        L.rth_renderer_pixels.argtypes = [C.c_void_p]
+        L.rth_renderer_pixels.restype = UP
+        L.rth_renderer_accumulator.argtypes = [C.c_void_p]
+        L.rth_renderer_accumulator.restype = FP
+        L.rth_renderer_ctx.argtypes = [C.c_void_p]
+        L.rth_renderer_ctx.restype = C.c_void_p
+        L.rth_renderer_error.argtypes = [C.c_void_p]
+        L.rth_renderer_error.restype = C.c_char_p
+        L.rth_renderer_last_ms.argtypes = [C.c_void_p]
+        L.rth_renderer_last_ms.restype = C.c_float
+        _host = L
+    return _host
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class HostScene:
+    """rtmi::Scene (raytracer_amd/host/scene.h): primitives + host-built BVH + marshalled upload arrays."""
+
+    def __init__(self, handle=None, owner=True):
+        self.L = host_lib()
+        self.h = handle if handle is not None else self.L.rth_scene_create()
+        self.owner = owner and handle is None
+
+    def __del__(self):
+        if getattr(self, "owner", False) and self.h:
+            self.L.rth_scene_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def default(cls, builder=REFERENCE_SAH, assets=ASSETS):
+        s = cls()
+        if s.L.rth_scene_make_default(s.h, assets.encode(), builder) != 0:
+            raise RtmiError("default scene: assets not found in %s" % assets)
+        return s
+
+    def make_room(self):
+        self.L.rth_scene_make_room(self.h)
+        return self
+
+    def add_sphere(self, pos, r, mat):
+        self.L.rth_scene_add_sphere(self.h, pos[0], pos[1], pos[2], r, C.byref(mat))
+
+    def add_triangles(self, v9, mat, offset=(0, 0, 0)):
+        v9 = np.ascontiguousarray(v9, np.float32).reshape(-1, 9)
+        self.L.rth_scene_add_triangles(self.h, _ptr(v9), len(v9), C.byref(mat), *[float(x) for x in offset])
+
+    def add_torus_knot(self, nu, nv, centre, mat, R=0.42, r=0.17, tube=0.075, p=2, q=3):
+        self.L.rth_scene_add_torus_knot(self.h, nu, nv, R, r, tube, p, q, centre[0], centre[1], centre[2], C.byref(mat))
+
+    def load_obj(self, path, mat, offset=(0, 0, 0)):
+        if self.L.rth_scene_load_obj(self.h, path.encode(), C.byref(mat), *[float(x) for x in offset]) != 0:
+            raise RtmiError("cannot load " + path)
+
+    def load_logo(self, assets=ASSETS):
+        if self.L.rth_scene_load_texture_raw(self.h, os.path.join(assets, "logo_128x64.rgb32").encode(), 128, 64) != 0:
+            raise RtmiError("logo texture missing")
+
+    def finalize(self, builder=REFERENCE_SAH):
+        self.L.rth_scene_finalize(self.h, builder)
+        return self
+
+    @property
+    def desc(self):
+        return self.L.rth_scene_desc(self.h).contents
+
+    def info(self):
+        out = np.zeros(7, np.int32)
+        self.L.rth_scene_info(self.h, _ptr(out))
+        return dict(zip(("quads", "spheres", "cubes", "planes", "triangles", "nodes_used", "max_depth"), out.tolist()))
+
+
+def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None):
+    """The mesh configs of SURVEY 8d: the reference room (6 planes + light quad) with three torus knots at
+    x = -1.5, 0, +1.5, z = 1.5 (the monkeys' places, scene.h:80-82): diffuse red, mirror, glass n=1.52.
+    n_tris_target is the total triangle count aimed for (nu = nv = sqrt(n/6))."""
+    s = HostScene().make_room()
+    s.load_logo()
+    n = max(8, int(round((n_tris_target / 6.0) ** 0.5)))
+    mats = materials or [Material(DIFFUSE, (0.93, 0.21, 0.21)), Material(MIRROR, (0.93, 0.93, 0.93)), Material(GLASS, (0.93, 0.93, 0.93), 1.52)]
+    for m, x in zip(mats, (-1.5, 0.0, 1.5)):
+        s.add_torus_knot(n, n, (x, 0.0, 1.5), m)
+    return s.finalize(builder)
+
+
+def seed_table(n):
+    out = np.zeros(n, np.uint32)
+    host_lib().rth_fill_seeds(_ptr(out), n)
+    return out
+
+
+def default_camera(w, h):
+    cam = np.zeros(16, np.float32)
+    host_lib().rth_camera_default(w, h, _ptr(cam))
+    return cam
+
+
+class Device:
+    """One rtmi_ctx (one GPU)."""
+
+    def __init__(self, width, height, device=0):
+        self.L = device_lib()
+        self.W, self.H = width, height
+        h = C.c_void_p()
+        r = self.L.rtmi_create(C.byref(h), device, width, height)
+        if r != 0:
+            raise RtmiError("rtmi_create failed with status %d (no GPU visible?)" % r)
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.L.rtmi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise RtmiError("rtmi status %d: %s" % (r, self.L.rtmi_last_error(self.h).decode()))
+
+    def upload(self, desc):
+        self._chk(self.L.rtmi_upload_scene(self.h, C.byref(desc)))
+
+    def set_camera(self, cam16):
+        cam16 = np.ascontiguousarray(cam16, np.float32)
+        self._chk(self.L.rtmi_set_camera(self.h, _ptr(cam16)))
+
+    def set_seeds(self, seeds):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        assert seeds.size == self.W * self.H
+        self._chk(self.L.rtmi_set_seeds(self.h, _ptr(seeds)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.rtmi_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_accumulator(self, dev_ptr):
+        self._chk(self.L.rtmi_set_accumulator(self.h, C.c_void_p(dev_ptr)))
+
+    def reset(self):
+        self._chk(self.L.rtmi_reset_accumulator(self.h))
+
+    def render(self, mode=PATHTRACING, sample_begin=0, sample_count=1, sample_stride=1, max_depth=5, aa=0):
+        self._chk(self.L.rtmi_render(self.h, mode, sample_begin, sample_count, sample_stride, max_depth, aa))
+
+    def sync(self):
+        self._chk(self.L.rtmi_synchronize(self.h))
+
+    def trace_primary(self):
+        obj = np.zeros(self.W * self.H, np.int32)
+        t = np.zeros(self.W * self.H, np.float32)
+        self._chk(self.L.rtmi_trace_primary(self.h, _ptr(obj), _ptr(t)))
+        return obj, t
+
+    def trace_rays(self, O, D, tmax, any_hit=False):
+        O = np.ascontiguousarray(O, np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, np.float32).reshape(-1, 3)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = len(O)
+        obj = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float32)
+        self._chk(self.L.rtmi_trace_rays(self.h, n, _ptr(O), _ptr(D), _ptr(tmax), int(any_hit), _ptr(obj), _ptr(t)))
+        return obj, t
+
+    def accumulator(self):
+        out = np.zeros((self.H, self.W, 4), np.float32)
+        self._chk(self.L.rtmi_read_accumulator(self.h, _ptr(out)))
+        return out
+
+    def finalize(self, frames, fx=None):
+        out = np.zeros((self.H, self.W), np.uint32)
+        self._chk(self.L.rtmi_finalize(self.h, _ptr(out), frames, C.byref(fx) if fx is not None else None))
+        return out
+
+    def postprocess(self, pixels, fx):
+        px = np.ascontiguousarray(pixels, np.uint32).copy()
+        h, w = px.shape
+        self._chk(self.L.rtmi_postprocess(self.h, _ptr(px), w, h, C.byref(fx)))
+        return px
+
+    def set_profiling(self, events=False, count_nodes=False):
+        self._chk(self.L.rtmi_set_profiling(self.h, int(events), int(count_nodes)))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.rtmi_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._chk(self.L.rtmi_reset_stats(self.h))
+
+
+class Renderer:
+    """rtmi::Renderer (raytracer_amd/host/renderer.h): the reference's Init()/Tick() surface."""
+
+    def __init__(self, width=1280, height=720, device=0):
+        self.L = host_lib()
+        self.W, self.H = width, height
+        self.h = self.L.rth_renderer_create(width, height, device)
+        self.scene = HostScene(self.L.rth_renderer_scene(self.h), owner=False)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.rth_renderer_destroy(self.h)
+            self.h = None
+
+    def init(self):
+        if self.L.rth_renderer_init(self.h) != 0:
+            raise RtmiError(self.L.rth_renderer_error(self.h).decode())
+
+    def upload_scene(self):
+        if self.L.rth_renderer_upload_scene(self.h) != 0:
+            raise RtmiError(self.L.rth_renderer_error(self.h).decode())
+
+    def tick(self, dt=0.0):
+        self.L.rth_renderer_tick(self.h, dt)
+        err = self.L.rth_renderer_error(self.h)
+        if err:
+            raise RtmiError(err.decode())
+
+    def set_mode(self, mode):
+        self.L.rth_renderer_set_mode(self.h, mode)
+
+    def set_aa(self, aa):
+        self.L.rth_renderer_set_aa(self.h, int(aa))
+
+    def set_depth(self, d):
+        self.L.rth_renderer_set_depth(self.h, d)
+
+    def set_spp_per_tick(self, n):
+        self.L.rth_renderer_set_spp_per_tick(self.h, n)
+
+    def set_postfx(self, fx, on=True):
+        self.L.rth_renderer_set_postfx(self.h, C.byref(fx), int(on))
+
+    @property
+    def frames(self):
+        return self.L.rth_renderer_frames(self.h)
+
+    def pixels(self):
+        return np.ctypeslib.as_array(self.L.rth_renderer_pixels(self.h), (self.H, self.W)).copy()
+
+    def accumulator(self):
+        p = self.L.rth_renderer_accumulator(self.h)
+        if not p:
+            raise RtmiError(self.L.rth_renderer_error(self.h).decode())
+        return np.ctypeslib.as_array(p, (self.H, self.W, 4)).copy()
+
+    def last_ms(self):
+        return self.L.rth_renderer_last_ms(self.h)

@@ -1,0 +1,95 @@
+"""Build helpers: compile the HIP device library, the C++ host mirror and (test infrastructure) the oracle.
+
+Everything is built in-tree with explicit compiler lines (hipcc cross-compiles gfx950 without a GPU):
+
+  raytracer_amd/librtmi.so        include/rtmi.h over the HIP kernels      (hipcc, -ffp-contract=off)
+  raytracer_amd/librtmi_host.so   Scene/BVH/Camera/Renderer host mirror    (g++,   -ffp-contract=off, OpenMP)
+  oracle/liboracle.so             CPU restatement, the parity checker      (g++,   -ffp-contract=off, OpenMP)
+  oracle/_ref/libref_WxH.so       the reference itself, dev container only (oracle/ref_build/build_ref.sh)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "raytracer_amd")
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+ORACLE = os.path.join(ROOT, "oracle")
+
+DEVICE_LIB = os.path.join(PKG, "librtmi.so")
+HOST_LIB = os.path.join(PKG, "librtmi_host.so")
+ORACLE_LIB = os.path.join(ORACLE, "liboracle.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_device(force=False):
+    srcs = [os.path.join(CSRC, "rtmi.hip"), os.path.join(CSRC, "rt_device.h"), os.path.join(ROOT, "include", "rtmi.h")]
+    if not force and not _newer(DEVICE_LIB, srcs):
+        return DEVICE_LIB
+    _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+          "-Wno-unused-result", "-o", DEVICE_LIB, srcs[0]])
+    return DEVICE_LIB
+
+
+def build_host(force=False):
+    srcs = [os.path.join(HOST, f) for f in ("bvh.cpp", "scene.cpp", "renderer.cpp", "capi.cpp")]
+    deps = srcs + [os.path.join(HOST, f) for f in ("bvh.h", "scene.h", "renderer.h", "rt_types.h")] + [os.path.join(ROOT, "include", "rtmi.h")]
+    if not force and not _newer(HOST_LIB, deps):
+        return HOST_LIB
+    build_device(force)
+    _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared", "-Wall",
+          "-o", HOST_LIB] + srcs + ["-L" + PKG, "-lrtmi", "-Wl,-rpath,$ORIGIN"])
+    return HOST_LIB
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE, "rt_oracle.cpp")]
+    deps = srcs + [os.path.join(ROOT, "include", "rtmi.h")]
+    if not force and not _newer(ORACLE_LIB, deps):
+        return ORACLE_LIB
+    _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared", "-Wall",
+          "-o", ORACLE_LIB] + srcs)
+    return ORACLE_LIB
+
+
+def build_ref(resolutions=((1280, 720), (320, 180))):
+    """Dev container only: compiles the reference where it lies.  No-op when /root/reference is absent."""
+    if not os.path.isdir(os.environ.get("RT_REF_ROOT", "/root/reference/Raytracer")):
+        return []
+    out = []
+    for w, h in resolutions:
+        lib = os.path.join(ORACLE, "_ref", "libref_%dx%d.so" % (w, h))
+        script = os.path.join(ORACLE, "ref_build", "build_ref.sh")
+        deps = [script, os.path.join(ORACLE, "ref_build", "ref_driver.cpp"), os.path.join(ORACLE, "ref_build", "shim", "precomp.h")]
+        if _newer(lib, deps):
+            _run(["bash", script, str(w), str(h)])
+        out.append(lib)
+    return out
+
+
+def build_all(force=False):
+    build_device(force)
+    build_host(force)
+    build_oracle(force)
+    build_ref()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,356 @@
+// rt_device.h -- gfx950 device code shared by the kernels in rtmi.hip: strict-IEEE vector helpers, xorshift32,
+// primitive intersection, slab tests, ordered BVH traversal with a per-lane LDS stack, hit attributes.
+//
+// Written for CDNA4 wave64.  Everything here must produce the same binary32 results as the reference CPU path
+// (primitive.h, bvh.h, template/scene.h, precomp.h math), so this translation unit is compiled with
+// -ffp-contract=off (no FMA fusion) and relies on hipcc's default correctly-rounded f32 divide and sqrt.
+// Operation order follows the cited reference lines; do not "simplify" expressions here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DONE 0xFFFFFFFFu
+#define RT_LEAF 0x80000000u
+#define RT_LEAF_FIRST_BITS 25
+#define RT_LEAF_FIRST_MASK ( ( 1u << RT_LEAF_FIRST_BITS ) - 1u )
+#define RT_LEAF_MAX_COUNT 64
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3( float x, float y, float z ) { f3 r; r.x = x, r.y = y, r.z = z; return r; }
+__device__ __forceinline__ f3 mk3( float4 v ) { return mk3( v.x, v.y, v.z ); }
+__device__ __forceinline__ f3 operator+( f3 a, f3 b ) { return mk3( a.x + b.x, a.y + b.y, a.z + b.z ); }
+__device__ __forceinline__ f3 operator-( f3 a, f3 b ) { return mk3( a.x - b.x, a.y - b.y, a.z - b.z ); }
+__device__ __forceinline__ f3 operator-( f3 a ) { return mk3( -a.x, -a.y, -a.z ); }
+__device__ __forceinline__ f3 operator*( f3 a, f3 b ) { return mk3( a.x * b.x, a.y * b.y, a.z * b.z ); }
+__device__ __forceinline__ f3 operator*( f3 a, float b ) { return mk3( a.x * b, a.y * b, a.z * b ); }
+__device__ __forceinline__ f3 operator*( float b, f3 a ) { return mk3( b * a.x, b * a.y, b * a.z ); }
+__device__ __forceinline__ f3 operator/( f3 a, float b ) { return mk3( a.x / b, a.y / b, a.z / b ); }
+__device__ __forceinline__ float dot3( f3 a, f3 b ) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // precomp.h:822
+__device__ __forceinline__ f3 cross3( f3 a, f3 b ) { return mk3( a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x ); } // :875
+__device__ __forceinline__ f3 normalize3( f3 v ) { float inv = 1.0f / sqrtf( dot3( v, v ) ); return v * inv; } // :490, 844
+__device__ __forceinline__ float magnitude3( f3 v ) { return sqrtf( v.x * v.x + v.y * v.y + v.z * v.z ); }     // :848
+__device__ __forceinline__ float sqrf_( float x ) { return x * x; }
+// std::min / std::max as the reference's scalar code resolves them (precomp.h:31): NaN-propagation is asymmetric
+__device__ __forceinline__ float smin( float a, float b ) { return ( b < a ) ? b : a; }
+__device__ __forceinline__ float smax( float a, float b ) { return ( a < b ) ? b : a; }
+
+// row-major mat4 rows 0..2 as three float4 (template.cpp:1021-1035)
+struct m34 { float4 r0, r1, r2; };
+__device__ __forceinline__ f3 xform_pos( f3 a, const m34& M )
+{
+	return mk3( M.r0.x * a.x + M.r0.y * a.y + M.r0.z * a.z + M.r0.w * 1.0f,
+		M.r1.x * a.x + M.r1.y * a.y + M.r1.z * a.z + M.r1.w * 1.0f,
+		M.r2.x * a.x + M.r2.y * a.y + M.r2.z * a.z + M.r2.w * 1.0f );
+}
+__device__ __forceinline__ f3 xform_vec( f3 a, const m34& M )
+{
+	return mk3( M.r0.x * a.x + M.r0.y * a.y + M.r0.z * a.z + M.r0.w * 0.0f,
+		M.r1.x * a.x + M.r1.y * a.y + M.r1.z * a.z + M.r1.w * 0.0f,
+		M.r2.x * a.x + M.r2.y * a.y + M.r2.z * a.z + M.r2.w * 0.0f );
+}
+
+// xorshift32 + RandomFloat (template.cpp:883-890)
+__device__ __forceinline__ uint32_t rng_next( uint32_t& s ) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+__device__ __forceinline__ float rng_float( uint32_t& s ) { return (float)rng_next( s ) * 2.3283064365387e-10f; }
+__device__ __forceinline__ uint32_t wang_hash( uint32_t s ) // template.cpp:871-878
+{
+	s = ( s ^ 61u ) ^ ( s >> 16 );
+	s *= 9u, s = s ^ ( s >> 4 );
+	s *= 0x27d4eb2du;
+	s = s ^ ( s >> 15 );
+	return s;
+}
+__device__ __forceinline__ uint32_t sample_seed( uint32_t s0, uint32_t s )
+{
+	uint32_t st = wang_hash( s0 + s * 0x9E3779B9u );
+	return st ? st : 1u;
+}
+
+// ---- device scene ------------------------------------------------------------------------------------------
+struct DMaterial { float4 color; float4 absorption; float ior; int type; int pad0, pad1; }; // 48 B
+
+struct DScene
+{
+	// BVH: pair p holds the two children of one interior node = two reference nodes (bvh.h:11-16) side by side,
+	// 64-byte aligned.  float4 x4: {Lmin.xyz, Lmax.x} {Lmax.yz, Lref, Lcnt} {Rmin.xyz, Rmax.x} {Rmax.yz, Rref, Rcnt}
+	const float4* __restrict__ pairs;
+	// leaf-ordered primitive records (position k == primitiveIdx[k]), 48 B: triangle {p1, tag 0} {e1, objIdx} {e2, -}
+	// sphere {pos, tag 1} {r2,0,0, objIdx} {-}
+	const float4* __restrict__ prims;
+	float root_min[3], root_max[3];
+	uint32_t root_ref;
+	int n_quads, n_spheres, n_cubes, n_planes, n_tris, n_bvh_prims;
+	const float4* __restrict__ quads;   // per quad 4 x float4: invT rows 0..2, {size,0,0,0}
+	const float4* __restrict__ cubes;   // per cube 8 x float4: invM rows 0..2, b0, b1, M rows 0..2
+	const float4* __restrict__ planes;  // (N, d)
+	// shading
+	const float4* __restrict__ primitives; // [total] scene.h:120-181
+	const uint8_t* __restrict__ mat_id;    // [total] -> materials
+	const DMaterial* __restrict__ materials;
+	const float* __restrict__ sphere_invr;
+	const uint32_t* __restrict__ texture;
+	int tex_w, tex_h;
+	float4 light_c1, light_c2, light_c3, light_emission, light_N;
+	float light_A, light_s;
+	float4 wl_pos[2], wl_color[2];
+	float wl_intensity;
+};
+
+struct RayHit { float t; int obj; int pos; };
+
+// ---- primitive intersection (closest-hit forms) ---------------------------------------------------------------
+// Quad::Intersect, primitive.h:284-295
+__device__ __forceinline__ void isect_quad( const DScene& s, int i, f3 O, f3 D, RayHit& h )
+{
+	m34 M; M.r0 = s.quads[4 * i], M.r1 = s.quads[4 * i + 1], M.r2 = s.quads[4 * i + 2];
+	const float size = s.quads[4 * i + 3].x;
+	const f3 o = xform_pos( O, M ), d = xform_vec( D, M );
+	const float t = o.y / -d.y;
+	if (t < h.t && t > 0)
+	{
+		const f3 I = o + t * d;
+		if (I.x > -size && I.x < size && I.z > -size && I.z < size) h.t = t, h.obj = i, h.pos = -1;
+	}
+}
+// Cube::Intersect, primitive.h:210-236
+__device__ __forceinline__ void isect_cube( const DScene& s, int i, f3 O, f3 D, RayHit& h )
+{
+	m34 M; M.r0 = s.cubes[8 * i], M.r1 = s.cubes[8 * i + 1], M.r2 = s.cubes[8 * i + 2];
+	const float4 b0 = s.cubes[8 * i + 3], b1 = s.cubes[8 * i + 4];
+	const f3 o = xform_pos( O, M ), d = xform_vec( D, M );
+	const float rDx = 1 / d.x, rDy = 1 / d.y, rDz = 1 / d.z;
+	const bool sx = d.x < 0, sy = d.y < 0, sz = d.z < 0;
+	float tmin = ( ( sx ? b1.x : b0.x ) - o.x ) * rDx;
+	float tmax = ( ( sx ? b0.x : b1.x ) - o.x ) * rDx;
+	const float tymin = ( ( sy ? b1.y : b0.y ) - o.y ) * rDy;
+	const float tymax = ( ( sy ? b0.y : b1.y ) - o.y ) * rDy;
+	if (tmin > tymax || tymin > tmax) return;
+	tmin = smax( tmin, tymin ), tmax = smin( tmax, tymax );
+	const float tzmin = ( ( sz ? b1.z : b0.z ) - o.z ) * rDz;
+	const float tzmax = ( ( sz ? b0.z : b1.z ) - o.z ) * rDz;
+	if (tmin > tzmax || tzmin > tmax) return;
+	tmin = smax( tmin, tzmin ), tmax = smin( tmax, tzmax );
+	const int obj = s.n_quads + s.n_spheres + i;
+	if (tmin > 0) { if (tmin < h.t) h.t = tmin, h.obj = obj, h.pos = -1; }
+	else if (tmax > 0) { if (tmax < h.t) h.t = tmax, h.obj = obj, h.pos = -1; }
+}
+// Plane::Intersect, primitive.h:154-158
+__device__ __forceinline__ void isect_plane( const DScene& s, int i, f3 O, f3 D, RayHit& h )
+{
+	const float4 p = s.planes[i];
+	const f3 N = mk3( p );
+	const float t = -( dot3( O, N ) + p.w ) / ( dot3( D, N ) );
+	if (t < h.t && t > 0) h.t = t, h.obj = s.n_quads + s.n_spheres + s.n_cubes + i, h.pos = -1;
+}
+// the non-BVH part of Scene::FindNearest + the plane loop of BVH::IntersectBVH (scene.h:361-362, bvh.h:498-502)
+__device__ __forceinline__ void isect_analytic( const DScene& s, f3 O, f3 D, RayHit& h )
+{
+	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );   // the reference tests quads[0] and cubes[0] only
+	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
+	for (int i = 0; i < s.n_planes; i++) isect_plane( s, i, O, D, h );
+}
+
+// One leaf-ordered primitive record against the ray.  Accepts a hit when it is closer, or equally far but
+// earlier in leaf order than the incumbent BVH hit: the reference's recursive left-first traversal visits leaves
+// in increasing primitiveIdx position and keeps the first of equal distances (strict `<`, primitive.h:68,116,122),
+// so "smallest (t, position)" is what it returns whatever the visiting order.
+template <bool ANY>
+__device__ __forceinline__ bool isect_prim( const DScene& s, int pos, f3 O, f3 D, RayHit& h )
+{
+	const float4 a = s.prims[3 * pos], b = s.prims[3 * pos + 1];
+	if (__float_as_int( a.w ) == 0)
+	{
+		// Triangle::Intersect, primitive.h:50-72 (edges precomputed on upload with the same two subtractions)
+		const float4 c = s.prims[3 * pos + 2];
+		const f3 p1 = mk3( a ), edge1 = mk3( b ), edge2 = mk3( c );
+		const f3 hh = cross3( D, edge2 );
+		const float det = dot3( edge1, hh );
+		if (det > -0.0001f && det < 0.0001f) return false;
+		const float f = 1 / det;
+		const f3 sv = O - p1;
+		const float u = f * dot3( sv, hh );
+		if (u < 0 || u > 1) return false;
+		const f3 q = cross3( sv, edge1 );
+		const float v = f * dot3( D, q );
+		if (v < 0 || u + v > 1) return false;
+		const float t = f * dot3( edge2, q );
+		if (t > 0.0001f && ( t < h.t || ( !ANY && t == h.t && pos < h.pos ) ))
+		{
+			h.t = t, h.obj = __float_as_int( b.w ), h.pos = pos;
+			return true;
+		}
+		return false;
+	}
+	// Sphere::Intersect, primitive.h:108-127
+	const f3 oc = O - mk3( a );
+	const float bb = dot3( oc, D );
+	const float cc = dot3( oc, oc ) - b.x;
+	float d = bb * bb - cc;
+	if (d <= 0) return false;
+	d = sqrtf( d );
+	float t = -bb - d;
+	if (t > 0 && ( t < h.t || ( !ANY && t == h.t && pos < h.pos ) )) { h.t = t, h.obj = __float_as_int( b.w ), h.pos = pos; return true; }
+	t = d - bb;
+	if (t > 0 && ( t < h.t || ( !ANY && t == h.t && pos < h.pos ) )) { h.t = t, h.obj = __float_as_int( b.w ), h.pos = pos; return true; }
+	return false;
+}
+
+// BVH::IntersectAABB (bvh.h:443-452) for both children of a pair.  EXACT reproduces std::min/std::max NaN behaviour
+// (needed only when a reciprocal direction component is infinite: 0*inf = NaN); otherwise v_min/v_max
+// give identical results on NaN-free data.
+template <bool EXACT>
+__device__ __forceinline__ void slab( float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 O, f3 rD, float& tmin, float& tmax )
+{
+	const float tx1 = ( bminx - O.x ) * rD.x, tx2 = ( bmaxx - O.x ) * rD.x;
+	const float ty1 = ( bminy - O.y ) * rD.y, ty2 = ( bmaxy - O.y ) * rD.y;
+	const float tz1 = ( bminz - O.z ) * rD.z, tz2 = ( bmaxz - O.z ) * rD.z;
+	if (EXACT)
+	{
+		tmin = smin( tx1, tx2 ), tmax = smax( tx1, tx2 );
+		tmin = smax( tmin, smin( ty1, ty2 ) ), tmax = smin( tmax, smax( ty1, ty2 ) );
+		tmin = smax( tmin, smin( tz1, tz2 ) ), tmax = smin( tmax, smax( tz1, tz2 ) );
+	}
+	else
+	{
+		tmin = fmaxf( fmaxf( fminf( tx1, tx2 ), fminf( ty1, ty2 ) ), fminf( tz1, tz2 ) );
+		tmax = fminf( fminf( fmaxf( tx1, tx2 ), fmaxf( ty1, ty2 ) ), fmaxf( tz1, tz2 ) );
+	}
+}
+
+struct TravCount { uint32_t pairs, prims; };
+
+// Ordered (near child first) traversal of the pair array with a per-lane stack in LDS.
+//   stack: this lane's column, entries at stack[level * stride]
+//   ANY:   stop at the first hit (Scene::IsOccluded / IntersectBVHShadowRay, bvh.h:640-688); the box test uses the
+//          fixed ray.t like the reference.  Otherwise closest hit (IntersectBVH, bvh.h:507-530) with the
+//          (t, position) rule above; boxes are kept while tmin <= t so that an equally distant, earlier
+//          primitive is still reached.
+// Returns true iff ANY and a hit was found.
+template <bool ANY, bool EXACT, bool COUNT>
+__device__ __forceinline__ bool traverse( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride, TravCount& cnt )
+{
+	float tmin, tmax;
+	slab<EXACT>( s.root_min[0], s.root_min[1], s.root_min[2], s.root_max[0], s.root_max[1], s.root_max[2], O, rD, tmin, tmax );
+	uint32_t cur = ( tmax >= tmin && tmin < h.t && tmax > 0 ) ? s.root_ref : RT_DONE;
+	int sp = 0;
+	while (true)
+	{
+		while (!( cur & RT_LEAF ))
+		{
+			const float4 q0 = s.pairs[4 * cur], q1 = s.pairs[4 * cur + 1], q2 = s.pairs[4 * cur + 2], q3 = s.pairs[4 * cur + 3];
+			if (COUNT) cnt.pairs++;
+			float tminL, tmaxL, tminR, tmaxR;
+			slab<EXACT>( q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, O, rD, tminL, tmaxL );
+			slab<EXACT>( q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, O, rD, tminR, tmaxR );
+			const bool hitL = tmaxL >= tminL && ( ANY ? tminL < h.t : tminL <= h.t ) && tmaxL > 0;
+			const bool hitR = tmaxR >= tminR && ( ANY ? tminR < h.t : tminR <= h.t ) && tmaxR > 0;
+			const uint32_t refL = __float_as_uint( q1.z ), refR = __float_as_uint( q3.z );
+			if (hitL && hitR)
+			{
+				const bool swap = tminR < tminL;
+				stack[sp * stride] = swap ? refL : refR;
+				sp++;
+				cur = swap ? refR : refL;
+			}
+			else if (hitL) cur = refL;
+			else if (hitR) cur = refR;
+			else if (sp > 0) cur = stack[--sp * stride];
+			else cur = RT_DONE;
+		}
+		if (cur == RT_DONE) break;
+		const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
+		for (int i = 0; i < count; i++)
+		{
+			if (COUNT) cnt.prims++;
+			const bool hit = isect_prim<ANY>( s, first + i, O, D, h );
+			if (ANY && hit) return true;
+		}
+		cur = sp > 0 ? stack[--sp * stride] : RT_DONE;
+	}
+	return false;
+}
+
+// Scene::FindNearest (scene.h:359-368): quads[0], cubes[0], planes, BVH.  h.t carries the ray's tmax in.
+template <bool COUNT>
+__device__ __forceinline__ void find_nearest( const DScene& s, f3 O, f3 D, RayHit& h, uint32_t* stack, int stride, TravCount& cnt )
+{
+	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z ); // Ray ctor, primitive.h:11
+	isect_analytic( s, O, D, h );
+	if (s.n_bvh_prims == 0) return;
+	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	if (__any( inexact )) traverse<false, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
+	else traverse<false, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
+}
+// Scene::IsOccluded (scene.h:369-379): quad, cube with the shrinking ray.t, then planes and BVH with early out.
+template <bool COUNT>
+__device__ __forceinline__ bool is_occluded( const DScene& s, f3 O, f3 D, float tmaxRay, uint32_t* stack, int stride, TravCount& cnt )
+{
+	RayHit h; h.t = tmaxRay, h.obj = -1, h.pos = -1;
+	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
+	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
+	if (h.obj != -1) return true;
+	for (int i = 0; i < s.n_planes; i++) { isect_plane( s, i, O, D, h ); if (h.obj != -1) return true; }
+	if (s.n_bvh_prims == 0) return false;
+	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	if (__any( inexact )) return traverse<true, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
+	return traverse<true, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
+}
+
+// ---- hit attributes (Scene::GetNormal / GetAlbedo / GetMaterial, scene.h:380-478) ---------------------------
+// Cube::GetNormal, primitive.h:237-254
+__device__ __forceinline__ f3 cube_normal( const DScene& s, int i, f3 I )
+{
+	m34 invM; invM.r0 = s.cubes[8 * i], invM.r1 = s.cubes[8 * i + 1], invM.r2 = s.cubes[8 * i + 2];
+	m34 M; M.r0 = s.cubes[8 * i + 5], M.r1 = s.cubes[8 * i + 6], M.r2 = s.cubes[8 * i + 7];
+	const float4 b0 = s.cubes[8 * i + 3], b1 = s.cubes[8 * i + 4];
+	const f3 o = xform_pos( I, invM );
+	f3 N = mk3( -1, 0, 0 );
+	const float d0 = fabsf( o.x - b0.x ), d1 = fabsf( o.x - b1.x );
+	const float d2 = fabsf( o.y - b0.y ), d3 = fabsf( o.y - b1.y );
+	const float d4 = fabsf( o.z - b0.z ), d5 = fabsf( o.z - b1.z );
+	float minDist = d0;
+	if (d1 < minDist) minDist = d1, N.x = 1;
+	if (d2 < minDist) minDist = d2, N = mk3( 0, -1, 0 );
+	if (d3 < minDist) minDist = d3, N = mk3( 0, 1, 0 );
+	if (d4 < minDist) minDist = d4, N = mk3( 0, 0, -1 );
+	if (d5 < minDist) minDist = d5, N = mk3( 0, 0, 1 );
+	return xform_vec( N, M );
+}
+// Plane::GetAlbedo, primitive.h:163-186
+__device__ __forceinline__ f3 plane_albedo( const DScene& s, f3 N, f3 I )
+{
+	if (N.y == 1)
+	{
+		int ix = (int)( I.x * 2 + 96.01f );
+		int iz = (int)( I.z * 2 + 96.01f );
+		if (ix == 98 && iz == 98) ix = (int)( I.x * 32.01f ), iz = (int)( I.z * 32.01f );
+		if (ix == 94 && iz == 98) ix = (int)( I.x * 64.01f ), iz = (int)( I.z * 64.01f );
+		const float c = ( ( ix + iz ) & 1 ) ? 1.0f : 0.3f;
+		return mk3( c, c, c );
+	}
+	else if (N.z == -1)
+	{
+		const int ix = (int)( ( I.x + 4 ) * ( 128.0f / 8 ) );
+		const int iy = (int)( ( 2 - I.y ) * ( 64.0f / 3 ) );
+		const uint32_t p = s.texture ? s.texture[( ix & 127 ) + ( iy & 63 ) * 128] : 0u;
+		return mk3( (float)( ( p >> 16 ) & 255 ), (float)( ( p >> 8 ) & 255 ), (float)( p & 255 ) ) * ( 1.0f / 255.0f );
+	}
+	return mk3( 0.93f, 0.93f, 0.93f );
+}
+struct HitAttr { f3 N; f3 albedo; const DMaterial* mat; };
+// wo = ray.D; WANT_ALBEDO mirrors where the reference calls GetAlbedo (renderer.cpp:145, 274, 324)
+__device__ __forceinline__ void hit_attributes( const DScene& s, int obj, f3 I, f3 wo, HitAttr& a )
+{
+	a.mat = &s.materials[s.mat_id[obj]];
+	const f3 color = mk3( a.mat->color );
+	int k = obj;
+	f3 N;
+	if (k < s.n_quads) { N = mk3( s.primitives[obj] ); a.albedo = mk3( 10, 10, 10 ); }                    // primitive.h:296-304
+	else if (( k -= s.n_quads ) < s.n_spheres) { N = ( I - mk3( s.primitives[obj] ) ) * s.sphere_invr[k]; a.albedo = color; } // :128-131
+	else if (( k -= s.n_spheres ) < s.n_cubes) { N = cube_normal( s, k, I ); a.albedo = color; }
+	else if (( k -= s.n_cubes ) < s.n_planes) { N = mk3( s.primitives[obj] ); a.albedo = plane_albedo( s, N, I ); }
+	else { N = mk3( s.primitives[obj] ); a.albedo = color; }
+	if (dot3( N, wo ) > 0) N = -N; // scene.h:412
+	a.N = N;
+}

@@ -1,0 +1,1200 @@
+// rtmi.hip -- librtmi.so: the C ABI of include/rtmi.h over hand-written gfx950 kernels.
+//
+// Wavefront path tracer (north star): per render batch of S samples x W*H pixels
+//   k_extend<PRIMARY>   ray generation fused with closest-hit traversal for bounce 0     (camera.h:28-35, scene.h:359-368)
+//   k_shade             material evaluation, NEE shadow-ray emission, Russian roulette, next ray; survivors and
+//                       shadow rays are appended to HBM queues with one atomic per wave (ballot + mbcnt prefix)
+//                                                                                        (renderer.cpp:246-365)
+//   k_connect           any-hit traversal of the shadow queue, E[slot] += contribution    (scene.h:369-379, renderer.cpp:339-344)
+//   k_extend            closest-hit traversal of the bounce queue
+//   k_accumulate        accumulator[p] += E[sample][p] in sample order                    (renderer.cpp:566-567)
+//   k_finalize, k_gamma, k_chroma, k_vignette                                             (precomp.h:431-465, postprocessing.h)
+//   k_whitted           Renderer::Trace for the non-path-tracing modes, one thread per pixel with an explicit
+//                       frame stack instead of recursion                                  (renderer.cpp:80-244)
+// No host read-back inside a bounce loop iteration: grids are sized from queue counts that arrive two bounces late
+// (counts never grow), kernels read the live count from device memory.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see raytracer_amd/build.py)
+#include "rt_device.h"
+#include "../../include/rtmi.h"
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <cstdlib>
+
+#define BLOCK 256
+
+// ---- per-path state, SoA over slots (slot = sample_in_batch * W*H + pixel) ------------------------------------
+struct PathState
+{
+	float4* o_t;  // ray origin, hit distance
+	float4* d_h;  // ray direction, hit object index (int bits)
+	float4* T_s;  // throughput, rng state (uint bits)
+	float4* E_f;  // radiance estimate of this sample so far, flags (bit0 lastSpecular, bit1 inside)
+};
+struct ShadowQueue
+{
+	float4* o_t;   // origin, tmax
+	float4* d_s;   // direction, slot (int bits)
+	float4* c;     // contribution if unoccluded
+};
+struct CamProp { float4 pos, tl, tr, bl; };
+
+struct DevCounters // zeroed per render batch
+{
+	uint32_t next[2];      // ping-pong bounce queue lengths
+	uint32_t shadow;       // shadow queue length of the current bounce
+	uint32_t pad;
+	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims;
+};
+
+// ---- wave-level queue append: one atomic per wave -------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_append( bool push, uint32_t* counter )
+{
+	const unsigned long long mask = __ballot( push );
+	if (mask == 0) return 0;
+	const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
+	uint32_t base = 0;
+	const int leader = __ffsll( (long long)mask ) - 1;
+	if ((int)( threadIdx.x & 63 ) == leader) base = atomicAdd( counter, (uint32_t)__popcll( mask ) );
+	base = __shfl( base, leader, 64 );
+	return base + rank;
+}
+__device__ __forceinline__ void wave_add64( unsigned long long v, unsigned long long* dst )
+{
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down( v, o, 64 );
+	if (( threadIdx.x & 63 ) == 0 && v) atomicAdd( dst, v );
+}
+
+// ---- primary ray, camera.h:28-35 / generatePrimaryRays.cl:4-33 -------------------------------------------------
+__device__ __forceinline__ void primary_ray( const CamProp& cam, float x, float y, float invW, float invH, f3& O, f3& D )
+{
+	const float u = x * invW, v = y * invH;
+	const f3 TL = mk3( cam.tl ), TR = mk3( cam.tr ), BL = mk3( cam.bl );
+	const f3 P = TL + u * ( TR - TL ) + v * ( BL - TL );
+	O = mk3( cam.pos );
+	D = normalize3( P - O );
+}
+
+// ---- extend: closest hit ---------------------------------------------------------------------------------------
+template <bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__( BLOCK ) void k_extend( DScene s, PathState st, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
+	uint32_t n_primary, CamProp cam, int W, int H, float invW, float invH, DevCounters* ctr )
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t n = PRIMARY ? n_primary : *count_ptr;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	if (i < n)
+	{
+		uint32_t slot;
+		f3 O, D;
+		if (PRIMARY)
+		{
+			slot = i;
+			const uint32_t p = i % (uint32_t)( W * H );
+			primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
+		}
+		else
+		{
+			slot = queue[i];
+			O = mk3( st.o_t[slot] ), D = mk3( st.d_h[slot] );
+		}
+		RayHit h; h.t = 1e34f, h.obj = -1, h.pos = -1;
+		find_nearest<COUNT>( s, O, D, h, lds_stack + threadIdx.x, BLOCK, tc );
+		if (PRIMARY)
+		{
+			st.o_t[slot] = make_float4( O.x, O.y, O.z, h.t );
+			st.d_h[slot] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+		}
+		else
+		{
+			st.o_t[slot].w = h.t;
+			st.d_h[slot].w = __int_as_float( h.obj );
+		}
+	}
+	if (COUNT)
+	{
+		wave_add64( tc.pairs, &ctr->extend_pairs );
+		wave_add64( tc.prims, &ctr->extend_prims );
+	}
+	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->extend_rays, (unsigned long long)n );
+}
+
+// ---- shade: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361) -----------------------------
+#define FLAG_SPECULAR 1u
+#define FLAG_INSIDE 2u
+
+template <bool PRIMARY>
+__global__ __launch_bounds__( BLOCK ) void k_shade( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
+	const uint32_t* __restrict__ count_ptr, uint32_t n_primary, const uint32_t* __restrict__ seeds, int WH, int sample_begin, int sample_stride,
+	uint32_t* next_count, uint32_t* shadow_count )
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t n = PRIMARY ? n_primary : *count_ptr;
+	bool push_next = false, push_shadow = false;
+	uint32_t slot = 0;
+	f3 newO, newD, shO, shD, contrib;
+	float shT = 0;
+	f3 T, E;
+	uint32_t rng = 0, flags = 0;
+	if (i < n)
+	{
+		slot = PRIMARY ? i : queue_in[i];
+		const float4 ot = st.o_t[slot], dh = st.d_h[slot];
+		const f3 O = mk3( ot ), D = mk3( dh );
+		const float t = ot.w;
+		const int obj = __float_as_int( dh.w );
+		if (PRIMARY)
+		{
+			const uint32_t p = slot % (uint32_t)WH, sidx = (uint32_t)sample_begin + ( slot / (uint32_t)WH ) * (uint32_t)sample_stride;
+			T = mk3( 1, 1, 1 ), E = mk3( 0, 0, 0 ), flags = FLAG_SPECULAR, rng = sample_seed( seeds[p], sidx );
+		}
+		else
+		{
+			const float4 ts = st.T_s[slot], ef = st.E_f[slot];
+			T = mk3( ts ), rng = __float_as_uint( ts.w ), E = mk3( ef ), flags = __float_as_uint( ef.w );
+		}
+		bool writeE = PRIMARY;
+		if (obj != -1)
+		{
+			const f3 I = O + t * D;
+			HitAttr a;
+			hit_attributes( s, obj, I, D, a );
+			const f3 N = a.N;
+			const int type = a.mat->type;
+			if (type == RTMI_LIGHT)
+			{
+				if (flags & FLAG_SPECULAR) E = E + T * mk3( s.light_emission ), writeE = true; // renderer.cpp:262-263
+			}
+			else if (type == RTMI_MIRROR) // renderer.cpp:266-271
+			{
+				const f3 refl = D - ( 2 * dot3( D, N ) ) * N;
+				newO = I + refl * 0.001f, newD = refl;
+				flags = FLAG_SPECULAR, push_next = true;
+			}
+			else if (type == RTMI_GLASS) // renderer.cpp:272-321
+			{
+				const float air = 1.0003f, ior = a.mat->ior;
+				float n1, n2;
+				f3 absorption = mk3( 1, 1, 1 );
+				if (flags & FLAG_INSIDE)
+				{
+					const float4 ab = a.mat->absorption;
+					absorption = mk3( expf( -ab.x * t ), expf( -ab.y * t ), expf( -ab.z * t ) );
+					n1 = ior, n2 = air;
+				}
+				else n1 = air, n2 = ior;
+				const float ratio = n1 / n2;
+				const float inc = dot3( N, -D );
+				const float k = 1.0f - sqrf_( ratio ) * ( 1.0f - sqrf_( inc ) );
+				const f3 refr = ratio * D + N * ( ratio * inc - sqrtf( k ) );
+				const float outc = dot3( -N, refr );
+				const double left = sqrf_( ( n1 * inc - ior * outc ) / ( n1 * inc + n2 * outc ) );
+				const double right = sqrf_( ( n1 * outc - ior * inc ) / ( n1 * outc + n2 * inc ) );
+				const float Fr = (float)( 0.5 * ( left + right ) );
+				T = T * ( a.albedo * absorption );
+				bool reflect = k < 0;
+				if (!reflect) reflect = rng_float( rng ) <= Fr; // short-circuit: no draw when k < 0
+				if (reflect)
+				{
+					const f3 refl = D - ( 2.0f * dot3( D, N ) ) * N;
+					newO = I + refl * 0.001f, newD = refl, flags = FLAG_SPECULAR;
+				}
+				else newO = I + refr * 0.001f, newD = refr, flags = FLAG_SPECULAR | FLAG_INSIDE; // renderer.cpp:317-318
+				push_next = true;
+			}
+			else // diffuse (and SUBSTANCE), renderer.cpp:322-361
+			{
+				const f3 BRDF = a.albedo / 3.14159265358979323846264f;
+				// Scene::RandomPointOnLight, scene.h:317-341
+				const f3 c1 = mk3( s.light_c1 ), c2 = mk3( s.light_c2 ), c3 = mk3( s.light_c3 ), Nl = mk3( s.light_N );
+				const f3 c1c2 = normalize3( c1 - c2 );
+				float len = rng_float( rng ) * s.light_s;
+				const f3 u = c1c2 * len;
+				const f3 c2c3 = normalize3( c3 - c2 );
+				len = rng_float( rng ) * s.light_s;
+				const f3 v = c2c3 * len;
+				const f3 lp = c2 + u + v - mk3( 0, 0.01f, 0 );
+				f3 L = lp - I;
+				const float dist = magnitude3( L );
+				L = normalize3( L );
+				if (dot3( N, L ) > 0 && dot3( Nl, -L ) > 0)
+				{
+					const float solidAngle = ( dot3( Nl, -L ) * s.light_A ) / sqrf_( dist );
+					const float lightPDF = 1.0f / solidAngle;
+					contrib = T * ( dot3( N, L ) / lightPDF ) * BRDF * mk3( s.light_emission );
+					shO = I + L * 0.001f, shD = L, shT = dist - 2.0f * 0.001f;
+					push_shadow = true;
+				}
+				// Russian roulette, renderer.cpp:347-352 (template clamp = fmaxf(a, fminf(f, b)) with ternaries)
+				float p = smax( a.albedo.z, smax( a.albedo.x, a.albedo.y ) );
+				p = p < 1.0f ? p : 1.0f;
+				p = 0.0f > p ? 0.0f : p;
+				if (!( p < rng_float( rng ) ))
+				{
+					T = T * ( 1.0f / p );
+					// Scene::DiffuseReflection, scene.h:517-532 (draw order x, y, z)
+					f3 R;
+					do
+					{
+						const float rx = rng_float( rng ) * 2.0f - 1.0f;
+						const float ry = rng_float( rng ) * 2.0f - 1.0f;
+						const float rz = rng_float( rng ) * 2.0f - 1.0f;
+						R = mk3( rx, ry, rz );
+					} while (magnitude3( R ) > 1.0f);
+					R = normalize3( R );
+					if (dot3( N, R ) < 0) R = -R;
+					const float hemiPDF = 1.0f / ( 3.14159265358979323846264f * 2.0f );
+					newO = I + R * 0.001f, newD = R;
+					T = T * ( ( dot3( N, R ) / hemiPDF ) * BRDF );
+					flags = 0, push_next = true;
+				}
+			}
+		}
+		if (push_next)
+		{
+			st.o_t[slot] = make_float4( newO.x, newO.y, newO.z, 1e34f );
+			st.d_h[slot] = make_float4( newD.x, newD.y, newD.z, __int_as_float( -1 ) );
+			st.T_s[slot] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+		}
+		if (push_next || writeE) st.E_f[slot] = make_float4( E.x, E.y, E.z, __uint_as_float( flags ) );
+	}
+	const uint32_t qi = wave_append( push_next, next_count );
+	if (push_next) queue_out[qi] = slot;
+	const uint32_t si = wave_append( push_shadow, shadow_count );
+	if (push_shadow)
+	{
+		sq.o_t[si] = make_float4( shO.x, shO.y, shO.z, shT );
+		sq.d_s[si] = make_float4( shD.x, shD.y, shD.z, __uint_as_float( slot ) );
+		sq.c[si] = make_float4( contrib.x, contrib.y, contrib.z, 0 );
+	}
+}
+
+// ---- connect: any hit over the shadow queue (renderer.cpp:339-344) ------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__( BLOCK ) void k_connect( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ count_ptr, DevCounters* ctr )
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t n = *count_ptr;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	if (i < n)
+	{
+		const float4 ot = sq.o_t[i], ds = sq.d_s[i];
+		const bool occ = is_occluded<COUNT>( s, mk3( ot ), mk3( ds ), ot.w, lds_stack + threadIdx.x, BLOCK, tc );
+		if (!occ)
+		{
+			const uint32_t slot = __float_as_uint( ds.w );
+			const float4 c = sq.c[i];
+			float4 e = st.E_f[slot];
+			e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
+			st.E_f[slot] = e;
+		}
+	}
+	if (COUNT)
+	{
+		wave_add64( tc.pairs, &ctr->shadow_pairs );
+		wave_add64( tc.prims, &ctr->shadow_prims );
+	}
+	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->shadow_rays, (unsigned long long)n );
+}
+
+// the shadow count of a bounce is consumed by k_connect of the same bounce; reset it for the next one
+__global__ void k_reset_shadow( DevCounters* ctr, int which_next ) { ctr->shadow = 0; ctr->next[which_next] = 0; }
+
+// ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
+__global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E_f, int WH, int S )
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= WH) return;
+	float4 a = acc[p];
+	for (int k = 0; k < S; k++)
+	{
+		const float4 e = E_f[(size_t)k * WH + p];
+		a.x += e.x, a.y += e.y, a.z += e.z, a.w += 0.0f;
+	}
+	acc[p] = a;
+}
+
+// ---- finalize: RGBF32_to_RGB8 (precomp.h:431-465, finalize.cl) ------------------------------------------------
+__global__ __launch_bounds__( BLOCK ) void k_finalize( const float4* __restrict__ acc, uint32_t* __restrict__ out, int n, int frames )
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= n) return;
+	float4 v = acc[p];
+	if (frames > 0) { const float f = (float)frames; v.x = v.x / f, v.y = v.y / f, v.z = v.z / f; }
+	// std::min(1.0f, x) = (x < 1.0f) ? x : 1.0f ; NaN -> 1.0f
+	const uint32_t r = (uint32_t)( 255.0f * ( v.x < 1.0f ? v.x : 1.0f ) );
+	const uint32_t g = (uint32_t)( 255.0f * ( v.y < 1.0f ? v.y : 1.0f ) );
+	const uint32_t b = (uint32_t)( 255.0f * ( v.z < 1.0f ? v.z : 1.0f ) );
+	out[p] = ( r << 16 ) + ( g << 8 ) + b;
+}
+
+// ---- post-processing (postprocessing.h:16-99) ----------------------------------------------------------------
+// gamma: per channel c -> (uint)(255 * pow(c/255, 1/gamma)); a function of the 8-bit input only, so the 256-entry
+// table is computed on the host with the same powf the CPU path uses and applied here.
+__global__ __launch_bounds__( BLOCK ) void k_gamma( uint32_t* __restrict__ px, int n, const uint32_t* __restrict__ lut )
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t c = px[p];
+	px[p] = ( lut[( c >> 16 ) & 255] << 16 ) + ( lut[( c >> 8 ) & 255] << 8 ) + lut[c & 255];
+}
+__global__ __launch_bounds__( BLOCK ) void k_chroma( const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int W, int H, float intensity )
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= W * H) return;
+	const int x = p % W, y = p / W;
+	const float cx = (float)W / 2.0f, cy = (float)H / 2.0f;
+	const float max_distance = sqrtf( cx * cx + cy * cy );
+	const float g_off = intensity, b_off = intensity * 2;
+	const float fx = (float)x, fy = (float)y;
+	const float ddx = cx - fx, ddy = cy - fy;
+	const float distance = sqrtf( ddx * ddx + ddy * ddy );
+	const float ratio = distance / max_distance;
+	const uint32_t r = ( src[p] & 0xFF0000 ) >> 16;
+	// dir = normalize(cord - center); at the centre pixel this is 0 * inf = NaN in the reference and the int cast is
+	// undefined: the offset is defined as 0 there.
+	const float vx = fx - cx, vy = fy - cy;
+	const float inv = 1.0f / sqrtf( vx * vx + vy * vy );
+	float dirx = vx * inv, diry = vy * inv;
+	if (!( dirx == dirx ) || !( diry == diry )) dirx = 0.0f, diry = 0.0f;
+	float c2x = fx + (float)(int)( dirx * g_off * ratio ), c2y = fy + (float)(int)( diry * g_off * ratio );
+	int nx = max( 0, min( (int)c2x, W - 1 ) ), ny = max( 0, min( (int)c2y, H - 1 ) );
+	const uint32_t g = ( src[nx + ny * W] & 0x00FF00 ) >> 8;
+	c2x = fx + (float)(int)( dirx * b_off * ratio ), c2y = fy + (float)(int)( diry * b_off * ratio );
+	nx = max( 0, min( (int)c2x, W - 1 ) ), ny = max( 0, min( (int)c2y, H - 1 ) );
+	const uint32_t b = src[nx + ny * W] & 0x0000FF;
+	dst[p] = ( r << 16 ) + ( g << 8 ) + b;
+}
+__global__ __launch_bounds__( BLOCK ) void k_vignette( uint32_t* __restrict__ px, int W, int H, float intensity )
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= W * H) return;
+	const int x = p % W, y = p / W;
+	const float cx = (float)W / 2.0f, cy = (float)H / 2.0f;
+	const float max_distance = sqrtf( cx * cx + cy * cy );
+	const float ddx = cx - (float)x, ddy = cy - (float)y;
+	const float distance = sqrtf( ddx * ddx + ddy * ddy );
+	const float q = 1 - ( distance * intensity / max_distance );
+	const float dimming = ( q < 0.0f ) ? 0.0f : q; // std::max(q, 0.0f)
+	const uint32_t c = px[p];
+	const uint32_t r = (uint32_t)( (float)( ( c & 0xFF0000 ) >> 16 ) * dimming );
+	const uint32_t g = (uint32_t)( (float)( ( c & 0x00FF00 ) >> 8 ) * dimming );
+	const uint32_t b = (uint32_t)( (float)( c & 0x0000FF ) * dimming );
+	px[p] = ( r << 16 ) + ( g << 8 ) + b;
+}
+
+// ---- parity hook: caller rays -----------------------------------------------------------------------------------
+__global__ __launch_bounds__( BLOCK ) void k_trace_rays( DScene s, int n, const float* __restrict__ O3, const float* __restrict__ D3, const float* __restrict__ tmax,
+	int any_hit, int* __restrict__ obj_out, float* __restrict__ t_out )
+{
+	extern __shared__ uint32_t lds_stack[];
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	const bool live = i < n;
+	const int k = live ? i : 0;
+	const f3 O = mk3( O3[3 * k], O3[3 * k + 1], O3[3 * k + 2] ), D = mk3( D3[3 * k], D3[3 * k + 1], D3[3 * k + 2] );
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	if (live)
+	{
+		if (any_hit)
+		{
+			const bool occ = is_occluded<false>( s, O, D, tmax[k], lds_stack + threadIdx.x, BLOCK, tc );
+			obj_out[k] = occ ? 1 : 0, t_out[k] = tmax[k];
+		}
+		else
+		{
+			RayHit h; h.t = tmax[k], h.obj = -1, h.pos = -1;
+			find_nearest<false>( s, O, D, h, lds_stack + threadIdx.x, BLOCK, tc );
+			obj_out[k] = h.obj, t_out[k] = h.t;
+		}
+	}
+}
+__global__ __launch_bounds__( BLOCK ) void k_copy_hits( PathState st, int n, int* __restrict__ obj_out, float* __restrict__ t_out )
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	obj_out[i] = __float_as_int( st.d_h[i].w ), t_out[i] = st.o_t[i].w;
+}
+
+// ---- Whitted / debug views: Renderer::Trace without recursion (renderer.cpp:80-244) ------------------------
+// Each pending call is a frame; a GLASS frame is visited up to three times (before the reflection child, before the
+// refraction child, after both).  Frames live in a per-thread slice of a global buffer (depth <= max_depth).
+struct WFrame
+{
+	f3 O, D;          // the ray of this call
+	float t;          // ray.t after FindNearest (needed by the glass absorption and Fresnel terms)
+	uint32_t inside;  // ray.inside
+	int stage;        // 0 = not started, 1 = waiting for reflection, 2 = waiting for refraction, 3 = mirror child
+	f3 aa;            // albedo * absorption (glass) or material.color (mirror)
+	f3 refl;          // reflectionColor
+	f3 N;
+	float n1, n2, ior, ratio, inc, k;
+};
+
+__device__ __forceinline__ f3 direct_illumination( const DScene& s, f3 I, f3 N, uint32_t* stack, int stride ) // scene.h:490-515
+{
+	f3 acc = mk3( 0, 0, 0 );
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	for (int i = 0; i < 2; i++)
+	{
+		const f3 dir = mk3( s.wl_pos[i] ) - I;
+		const f3 dirN = normalize3( dir );
+		const float eps = 0.001f;
+		const f3 so = I + dirN * eps;
+		const float mag = magnitude3( dir );
+		const float st = mag - eps * 2;
+		if (!is_occluded<false>( s, so, dirN, st, stack, stride, tc ))
+		{
+			const float distanceEnergy = 1 / sqrf_( st );
+			const float d = dot3( N, dirN );
+			const float angularEnergy = ( d < 0.0f ) ? 0.0f : d; // std::max(d, 0.0f)
+			acc = acc + mk3( s.wl_color[i] ) * s.wl_intensity * distanceEnergy * angularEnergy;
+		}
+	}
+	return acc;
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa,
+	WFrame* __restrict__ frames, float4* __restrict__ acc )
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t* stack = lds_stack + threadIdx.x;
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= W * H) return;
+	const int x = p % W, y = p / W;
+	WFrame* fr = frames + (size_t)p * ( max_depth + 1 );
+	const float pat[8] = { -1.0f / 8.0f, 3.0f / 8.0f, 3.0f / 8.0f, 1.0f / 8.0f, -3.0f / 8.0f, -1.0f / 8.0f, 1.0f / 8.0f, -3.0f / 8.0f }; // renderer.h:31-36
+	float4 total = make_float4( 0, 0, 0, 0 );
+	const int nsamp = aa ? 4 : 1;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	for (int smp = 0; smp < nsamp; smp++)
+	{
+		f3 O, D;
+		const float sx = aa ? (float)x + pat[2 * smp] : (float)x, sy = aa ? (float)y + pat[2 * smp + 1] : (float)y;
+		primary_ray( cam, sx, sy, invW, invH, O, D );
+		int depth = 0;
+		fr[0].O = O, fr[0].D = D, fr[0].inside = 0, fr[0].stage = 0;
+		f3 ret = mk3( 0, 0, 0 ); // value returned by the most recently finished call
+		while (depth >= 0)
+		{
+			WFrame& f = fr[depth];
+			if (f.stage == 0)
+			{
+				if (depth >= max_depth) { ret = mk3( 0, 0, 0 ), depth--; continue; } // renderer.cpp:135-136
+				RayHit h; h.t = 1e34f, h.obj = -1, h.pos = -1;
+				find_nearest<false>( s, f.O, f.D, h, stack, BLOCK, tc );
+				if (h.obj == -1) { ret = mk3( 0, 0, 0 ), depth--; continue; }
+				const f3 I = f.O + h.t * f.D;
+				HitAttr a;
+				hit_attributes( s, h.obj, I, f.D, a );
+				const int type = a.mat->type;
+				if (mode == RTMI_ALBEDO) { ret = a.albedo, depth--; continue; }
+				if (mode == RTMI_NORMAL) { ret = ( a.N + mk3( 1, 1, 1 ) ) * 0.5f, depth--; continue; }
+				if (mode == RTMI_DISTANCE) { ret = 0.1f * mk3( h.t, h.t, h.t ), depth--; continue; }
+				if (type == RTMI_DIFFUSE || type == RTMI_LIGHT)
+				{
+					ret = a.albedo / 3.14159265358979323846264f * direct_illumination( s, I, a.N, stack, BLOCK );
+					depth--;
+				}
+				else if (type == RTMI_MIRROR)
+				{
+					const f3 refl = f.D - ( 2 * dot3( f.D, a.N ) ) * a.N;
+					f.aa = mk3( a.mat->color ), f.stage = 3;
+					WFrame& c = fr[depth + 1];
+					c.O = I + refl * 0.001f, c.D = refl, c.inside = 0, c.stage = 0;
+					depth++;
+				}
+				else if (type == RTMI_GLASS) // ComputePixelColorGlass, renderer.cpp:80-128
+				{
+					const f3 refl = f.D - 2.0f * ( dot3( f.D, a.N ) ) * a.N;
+					const float air = 1.0003f, ior = a.mat->ior;
+					f3 absorption = mk3( 1, 1, 1 );
+					if (f.inside)
+					{
+						const float4 ab = a.mat->absorption;
+						absorption = mk3( expf( -ab.x * h.t ), expf( -ab.y * h.t ), expf( -ab.z * h.t ) );
+						f.n1 = ior, f.n2 = air;
+					}
+					else f.n1 = air, f.n2 = ior;
+					f.ior = ior, f.ratio = f.n1 / f.n2, f.aa = a.albedo * absorption, f.N = a.N, f.t = h.t;
+					f.inc = dot3( a.N, -f.D );
+					f.k = 1.0f - sqrf_( f.ratio ) * ( 1.0f - sqrf_( f.inc ) );
+					f.stage = 1;
+					WFrame& c = fr[depth + 1];
+					c.O = I + refl * 0.001f, c.D = refl, c.inside = f.inside ? 1u : 0u, c.stage = 0;
+					// keep the hit point for the refraction child
+					f.refl = I; // temporarily holds I until the reflection colour replaces it
+					depth++;
+				}
+				else { ret = mk3( 0, 0, 0 ), depth--; } // SUBSTANCE: the reference falls out of the switch (UB); defined as black
+			}
+			else if (f.stage == 3) { ret = f.aa * ret, depth--; } // material.color * Trace(...)
+			else if (f.stage == 1)
+			{
+				const f3 I = f.refl;
+				const f3 reflectionColor = f.aa * ret;
+				if (f.k < 0) { ret = reflectionColor, depth--; continue; }
+				const f3 refr = f.ratio * f.D + f.N * ( f.ratio * f.inc - sqrtf( f.k ) );
+				f.refl = reflectionColor, f.stage = 2;
+				// outcoming angle needs refr again after the child returns: recompute then (same expression, same bits)
+				WFrame& c = fr[depth + 1];
+				c.O = I + refr * 0.001f, c.D = refr, c.inside = f.inside ? 0u : 1u, c.stage = 0;
+				depth++;
+			}
+			else // stage 2: both children done
+			{
+				const f3 refractionColor = f.aa * ret;
+				const f3 refr = f.ratio * f.D + f.N * ( f.ratio * f.inc - sqrtf( f.k ) );
+				const float outc = dot3( -f.N, refr );
+				const double left = sqrf_( ( f.n1 * f.inc - f.ior * outc ) / ( f.n1 * f.inc + f.n2 * outc ) );
+				const double right = sqrf_( ( f.n1 * outc - f.ior * f.inc ) / ( f.n1 * outc + f.n2 * f.inc ) );
+				const float Fr = (float)( 0.5 * ( left + right ) );
+				ret = Fr * f.refl + ( 1 - Fr ) * refractionColor;
+				depth--;
+			}
+		}
+		total.x += ret.x, total.y += ret.y, total.z += ret.z;
+	}
+	if (aa) total.x /= 4.0f, total.y /= 4.0f, total.z /= 4.0f, total.w /= 4.0f;
+	acc[p] = total;
+}
+
+// =================================================================================================================
+// host side
+// =================================================================================================================
+struct rtmi_ctx
+{
+	int device = 0, W = 0, H = 0;
+	hipStream_t own_stream = 0, stream = 0;
+	std::string err;
+	bool has_scene = false;
+	DScene ds = {};
+	std::vector<void*> scene_allocs;
+	int stack_depth = 8;
+	CamProp cam = {};
+	uint32_t* seeds = 0;
+	float4* accum_own = 0;
+	float4* accum = 0;
+	uint32_t* pixels = 0, *pixels2 = 0, *gamma_lut = 0;
+	// path tracing state, sized for `batch` samples in flight
+	int batch = 0;
+	PathState st = {};
+	ShadowQueue sq = {};
+	uint32_t* queue[2] = { 0, 0 };
+	DevCounters* ctr = 0;
+	uint32_t* host_counts = 0; // pinned ring of read-back queue lengths
+	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
+	WFrame* frames = 0;
+	int frames_depth = 0;
+	// stats / profiling
+	bool prof_events = false, count_nodes = false;
+	rtmi_stats stats = {};
+	struct TimedEv { hipEvent_t a, b; int cls; };
+	std::vector<TimedEv> timed;
+	std::vector<hipEvent_t> ev_pool;
+};
+
+#define HIPCHK( call )                                                                                                         \
+	do {                                                                                                                       \
+		hipError_t e_ = ( call );                                                                                              \
+		if (e_ != hipSuccess) { c->err = std::string( #call ) + ": " + hipGetErrorString( e_ ); return RTMI_ERR_HIP; }        \
+	} while (0)
+
+static int fail( rtmi_ctx* c, int code, const std::string& msg ) { if (c) c->err = msg; return code; }
+static inline int nblocks( size_t n ) { return (int)( ( n + BLOCK - 1 ) / BLOCK ); }
+
+template <typename T> static int dev_alloc( rtmi_ctx* c, T** p, size_t count, std::vector<void*>* track = 0 )
+{
+	*p = 0;
+	if (count == 0) count = 1;
+	void* q = 0;
+	hipError_t e = hipMalloc( &q, count * sizeof( T ) );
+	if (e != hipSuccess) { c->err = std::string( "hipMalloc: " ) + hipGetErrorString( e ); return RTMI_ERR_NOMEM; }
+	*p = (T*)q;
+	if (track) track->push_back( q );
+	return RTMI_OK;
+}
+template <typename T> static int dev_upload( rtmi_ctx* c, T** p, const T* src, size_t count, std::vector<void*>* track )
+{
+	int r = dev_alloc( c, p, count, track );
+	if (r) return r;
+	if (count) HIPCHK( hipMemcpy( *p, src, count * sizeof( T ), hipMemcpyHostToDevice ) );
+	return RTMI_OK;
+}
+
+static hipEvent_t get_event( rtmi_ctx* c )
+{
+	if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+	hipEvent_t e; (void)hipEventCreate( &e ); return e;
+}
+struct ScopedTimer // records a pair of events around a launch when profiling is on
+{
+	rtmi_ctx* c; int cls; hipEvent_t a = 0, b = 0;
+	ScopedTimer( rtmi_ctx* c, int cls ) : c( c ), cls( cls ) { if (c->prof_events) { a = get_event( c ), b = get_event( c ); (void)hipEventRecord( a, c->stream ); } }
+	~ScopedTimer() { if (c->prof_events) { (void)hipEventRecord( b, c->stream ); c->timed.push_back( { a, b, cls } ); } }
+};
+static void resolve_timers( rtmi_ctx* c )
+{
+	for (auto& t : c->timed)
+	{
+		float ms = 0;
+		if (hipEventSynchronize( t.b ) == hipSuccess && hipEventElapsedTime( &ms, t.a, t.b ) == hipSuccess)
+		{
+			if (t.cls == 0) c->stats.ms_extend += ms, c->stats.n_extend_launches++;
+			else if (t.cls == 1) c->stats.ms_shade += ms, c->stats.n_shade_launches++;
+			else if (t.cls == 2) c->stats.ms_connect += ms, c->stats.n_connect_launches++;
+			else c->stats.ms_other += ms;
+		}
+		c->ev_pool.push_back( t.a ), c->ev_pool.push_back( t.b );
+	}
+	c->timed.clear();
+}
+
+static void free_scene( rtmi_ctx* c )
+{
+	for (void* p : c->scene_allocs) (void)hipFree( p );
+	c->scene_allocs.clear();
+	c->has_scene = false;
+}
+static void free_batch( rtmi_ctx* c )
+{
+	void* ps[] = { c->st.o_t, c->st.d_h, c->st.T_s, c->st.E_f, c->sq.o_t, c->sq.d_s, c->sq.c, c->queue[0], c->queue[1] };
+	for (void* p : ps) if (p) (void)hipFree( p );
+	c->st = PathState{}, c->sq = ShadowQueue{}, c->queue[0] = c->queue[1] = 0, c->batch = 0;
+}
+static int ensure_batch( rtmi_ctx* c, int S )
+{
+	if (c->batch >= S) return RTMI_OK;
+	free_batch( c );
+	const size_t n = (size_t)S * c->W * c->H;
+	int r;
+	if (( r = dev_alloc( c, &c->st.o_t, n ) ) || ( r = dev_alloc( c, &c->st.d_h, n ) ) || ( r = dev_alloc( c, &c->st.T_s, n ) ) || ( r = dev_alloc( c, &c->st.E_f, n ) ) ||
+		( r = dev_alloc( c, &c->sq.o_t, n ) ) || ( r = dev_alloc( c, &c->sq.d_s, n ) ) || ( r = dev_alloc( c, &c->sq.c, n ) ) ||
+		( r = dev_alloc( c, &c->queue[0], n ) ) || ( r = dev_alloc( c, &c->queue[1], n ) )) { free_batch( c ); return r; }
+	c->batch = S;
+	return RTMI_OK;
+}
+
+extern "C" {
+
+const char* rtmi_version( void ) { return "rtmi 0.1 (gfx950)"; }
+const char* rtmi_last_error( rtmi_ctx* c ) { return c ? c->err.c_str() : "null context"; }
+
+int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
+{
+	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << 28 )) return RTMI_ERR_INVALID;
+	*out = 0;
+	rtmi_ctx* c = new rtmi_ctx;
+	c->device = device_id, c->W = width, c->H = height;
+	auto bail = [&]( int code ) { delete c; return code; };
+	int ndev = 0;
+	if (hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0) { fprintf( stderr, "rtmi_create: no HIP device available\n" ); return bail( RTMI_ERR_HIP ); }
+	if (device_id < 0 || device_id >= ndev) return bail( RTMI_ERR_INVALID );
+	if (hipSetDevice( device_id ) != hipSuccess) return bail( RTMI_ERR_HIP );
+	if (hipStreamCreateWithFlags( &c->own_stream, hipStreamNonBlocking ) != hipSuccess) return bail( RTMI_ERR_HIP );
+	c->stream = c->own_stream;
+	const size_t n = (size_t)width * height;
+	if (dev_alloc( c, &c->seeds, n ) || dev_alloc( c, &c->accum_own, n ) || dev_alloc( c, &c->pixels, n ) || dev_alloc( c, &c->pixels2, n ) ||
+		dev_alloc( c, &c->gamma_lut, 256 ) || dev_alloc( c, &c->ctr, 1 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+	c->accum = c->accum_own;
+	if (hipHostMalloc( (void**)&c->host_counts, 4 * sizeof( uint32_t ), hipHostMallocDefault ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+	for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags( &c->count_ev[i], hipEventDisableTiming ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_HIP; }
+	(void)hipMemset( c->accum_own, 0, n * sizeof( float4 ) );
+	(void)hipMemset( c->seeds, 0, n * sizeof( uint32_t ) );
+	(void)hipMemset( c->ctr, 0, sizeof( DevCounters ) );
+	// default camera, camera.h:20-23
+	const float aspect = (float)width / (float)height;
+	c->cam.pos = make_float4( 0, 0, -2, 0 ), c->cam.tl = make_float4( -aspect, 1, 0, 0 ), c->cam.tr = make_float4( aspect, 1, 0, 0 ), c->cam.bl = make_float4( -aspect, -1, 0, 0 );
+	*out = c;
+	return RTMI_OK;
+}
+
+int rtmi_destroy( rtmi_ctx* c )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	(void)hipSetDevice( c->device );
+	(void)hipDeviceSynchronize();
+	resolve_timers( c );
+	free_scene( c ), free_batch( c );
+	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->ctr, c->frames };
+	for (void* p : ps) if (p) (void)hipFree( p );
+	if (c->host_counts) (void)hipHostFree( c->host_counts );
+	for (int i = 0; i < 4; i++) if (c->count_ev[i]) (void)hipEventDestroy( c->count_ev[i] );
+	for (auto e : c->ev_pool) (void)hipEventDestroy( e );
+	if (c->own_stream) (void)hipStreamDestroy( c->own_stream );
+	delete c;
+	return RTMI_OK;
+}
+
+int rtmi_set_stream( rtmi_ctx* c, void* s )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	c->stream = s ? (hipStream_t)s : c->own_stream;
+	return RTMI_OK;
+}
+
+int rtmi_synchronize( rtmi_ctx* c )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	resolve_timers( c );
+	return RTMI_OK;
+}
+
+// Validates the reference-layout node array and repacks it: pair k = nodes[3+2k], nodes[4+2k] (the reference
+// allocates children in adjacent pairs starting at node 3), interior leftFirst -> pair index, leaf -> encoded range.
+int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
+{
+	if (!c || !d) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	if (d->n_quads < 0 || d->n_spheres < 0 || d->n_cubes < 0 || d->n_planes < 0 || d->n_triangles < 0) return fail( c, RTMI_ERR_INVALID, "negative primitive count" );
+	const int nbvh = d->n_spheres + d->n_triangles;
+	const long long total = (long long)d->n_quads + d->n_spheres + d->n_cubes + d->n_planes + d->n_triangles;
+	if (total > ( 1ll << 30 )) return fail( c, RTMI_ERR_INVALID, "too many primitives" );
+	if (nbvh > (int)RT_LEAF_FIRST_MASK) return fail( c, RTMI_ERR_BVH, "more than 2^25-1 BVH primitives" );
+	if (total > 0 && ( !d->primitives || !d->albedo || !d->material_type || !d->ior || !d->absorption )) return fail( c, RTMI_ERR_INVALID, "null per-primitive array" );
+	if (( d->n_quads && ( !d->quad_inv_T || !d->quad_size ) ) || ( d->n_spheres && ( !d->sphere_info || !d->sphere_invr ) ) ||
+		( d->n_cubes && ( !d->cube_M || !d->cube_inv_M || !d->cube_b ) ) || ( d->n_triangles && !d->tri_verts )) return fail( c, RTMI_ERR_INVALID, "null geometry array" );
+	if (nbvh > 0 && ( !d->nodes || !d->prim_idx || d->n_nodes < 3 )) return fail( c, RTMI_ERR_BVH, "BVH arrays missing" );
+	if (d->texture && ( d->tex_w != 128 || d->tex_h != 64 )) return fail( c, RTMI_ERR_INVALID, "texture must be 128x64 (primitive.h:179-181)" );
+
+	DScene ds = {};
+	std::vector<void*> allocs;
+	auto bail = [&]( int code ) { for (void* p : allocs) (void)hipFree( p ); return code; };
+	int r;
+	int maxDepth = 0;
+	ds.n_quads = d->n_quads, ds.n_spheres = d->n_spheres, ds.n_cubes = d->n_cubes, ds.n_planes = d->n_planes, ds.n_tris = d->n_triangles, ds.n_bvh_prims = nbvh;
+	if (nbvh > 0)
+	{
+		const int nn = d->n_nodes;
+		if (( nn - 3 ) % 2 != 0) return fail( c, RTMI_ERR_BVH, "n_nodes must be 3 + 2*pairs" );
+		const int npairs = ( nn - 3 ) / 2;
+		auto encode = [&]( const rtmi_bvh_node& n, uint32_t& ref ) -> bool {
+			if (n.primitiveCount > 0)
+			{
+				if (n.primitiveCount > RT_LEAF_MAX_COUNT || n.leftFirst < 0 || (long long)n.leftFirst + n.primitiveCount > nbvh) return false;
+				ref = RT_LEAF | ( (uint32_t)( n.primitiveCount - 1 ) << RT_LEAF_FIRST_BITS ) | (uint32_t)n.leftFirst;
+				return true;
+			}
+			if (n.primitiveCount < 0 || n.leftFirst < 3 || n.leftFirst + 1 >= nn || ( ( n.leftFirst - 3 ) & 1 )) return false;
+			ref = (uint32_t)( ( n.leftFirst - 3 ) / 2 );
+			return true; };
+		const rtmi_bvh_node& root = d->nodes[2];
+		if (!encode( root, ds.root_ref )) return fail( c, RTMI_ERR_BVH, "bad root node (leaf larger than 64 primitives or index out of range)" );
+		ds.root_min[0] = root.aabbMinx, ds.root_min[1] = root.aabbMiny, ds.root_min[2] = root.aabbMinz;
+		ds.root_max[0] = root.aabbMaxx, ds.root_max[1] = root.aabbMaxy, ds.root_max[2] = root.aabbMaxz;
+		std::vector<float4> pairs( (size_t)( npairs > 0 ? npairs : 1 ) * 4, make_float4( 0, 0, 0, 0 ) );
+		for (int k = 0; k < npairs; k++)
+		{
+			const rtmi_bvh_node& L = d->nodes[3 + 2 * k], &R = d->nodes[4 + 2 * k];
+			uint32_t rl, rr;
+			if (!encode( L, rl ) || !encode( R, rr )) return fail( c, RTMI_ERR_BVH, "bad node (leaf larger than 64 primitives or index out of range)" );
+			pairs[4 * (size_t)k + 0] = make_float4( L.aabbMinx, L.aabbMiny, L.aabbMinz, L.aabbMaxx );
+			float4 q1 = make_float4( L.aabbMaxy, L.aabbMaxz, 0, 0 ); memcpy( &q1.z, &rl, 4 ); memcpy( &q1.w, &L.primitiveCount, 4 );
+			pairs[4 * (size_t)k + 1] = q1;
+			pairs[4 * (size_t)k + 2] = make_float4( R.aabbMinx, R.aabbMiny, R.aabbMinz, R.aabbMaxx );
+			float4 q3 = make_float4( R.aabbMaxy, R.aabbMaxz, 0, 0 ); memcpy( &q3.z, &rr, 4 ); memcpy( &q3.w, &R.primitiveCount, 4 );
+			pairs[4 * (size_t)k + 3] = q3;
+		}
+		// walk the tree: every pair reachable exactly once (no cycles / sharing), depth bound for the traversal stack
+		{
+			std::vector<uint8_t> seen( npairs > 0 ? npairs : 1, 0 );
+			std::vector<std::pair<uint32_t, int>> stk;
+			if (!( ds.root_ref & RT_LEAF )) stk.push_back( { ds.root_ref, 1 } );
+			size_t visited = 0;
+			while (!stk.empty())
+			{
+				auto [p, dep] = stk.back();
+				stk.pop_back();
+				if (p >= (uint32_t)npairs || seen[p]) return fail( c, RTMI_ERR_BVH, "node array is not a tree" );
+				seen[p] = 1, visited++;
+				maxDepth = std::max( maxDepth, dep );
+				uint32_t rl, rr;
+				memcpy( &rl, &pairs[4 * (size_t)p + 1].z, 4 ), memcpy( &rr, &pairs[4 * (size_t)p + 3].z, 4 );
+				if (!( rl & RT_LEAF )) stk.push_back( { rl, dep + 1 } );
+				if (!( rr & RT_LEAF )) stk.push_back( { rr, dep + 1 } );
+			}
+			if (maxDepth > RTMI_MAX_BVH_DEPTH) return fail( c, RTMI_ERR_BVH, "BVH deeper than RTMI_MAX_BVH_DEPTH" );
+		}
+		// leaf-ordered primitive records
+		std::vector<float4> prims( (size_t)nbvh * 3 );
+		const int triBase = d->n_quads + d->n_spheres + d->n_cubes + d->n_planes;
+		for (int k = 0; k < nbvh; k++)
+		{
+			const int pi = d->prim_idx[k];
+			if (pi < 0 || pi >= nbvh) return fail( c, RTMI_ERR_BVH, "prim_idx out of range" );
+			float4 a, b, cc = make_float4( 0, 0, 0, 0 );
+			if (pi < d->n_spheres)
+			{
+				const float* si = d->sphere_info + 4 * (size_t)pi;
+				a = make_float4( si[0], si[1], si[2], __builtin_bit_cast( float, 1 ) );
+				b = make_float4( si[3], 0, 0, __builtin_bit_cast( float, d->n_quads + pi ) );
+			}
+			else
+			{
+				const int ti = pi - d->n_spheres;
+				const float* v = d->tri_verts + 12 * (size_t)ti;
+				// edge1 = pos2 - pos1, edge2 = pos3 - pos1 (primitive.h:55-56), same two binary32 subtractions
+				a = make_float4( v[0], v[1], v[2], __builtin_bit_cast( float, 0 ) );
+				b = make_float4( v[4] - v[0], v[5] - v[1], v[6] - v[2], __builtin_bit_cast( float, triBase + ti ) );
+				cc = make_float4( v[8] - v[0], v[9] - v[1], v[10] - v[2], 0 );
+			}
+			prims[3 * (size_t)k] = a, prims[3 * (size_t)k + 1] = b, prims[3 * (size_t)k + 2] = cc;
+		}
+		float4* dp = 0, *dq = 0;
+		if (( r = dev_upload( c, &dp, pairs.data(), pairs.size(), &allocs ) ) || ( r = dev_upload( c, &dq, prims.data(), prims.size(), &allocs ) )) return bail( r );
+		ds.pairs = dp, ds.prims = dq;
+	}
+	else ds.root_ref = RT_DONE;
+	// analytic primitives
+	{
+		std::vector<float4> q( (size_t)std::max( d->n_quads, 1 ) * 4 ), cu( (size_t)std::max( d->n_cubes, 1 ) * 8 ), pl( std::max( d->n_planes, 1 ) );
+		for (int i = 0; i < d->n_quads; i++)
+		{
+			memcpy( &q[4 * (size_t)i], d->quad_inv_T + 16 * (size_t)i, 48 );
+			q[4 * (size_t)i + 3] = make_float4( d->quad_size[i], 0, 0, 0 );
+		}
+		for (int i = 0; i < d->n_cubes; i++)
+		{
+			memcpy( &cu[8 * (size_t)i], d->cube_inv_M + 16 * (size_t)i, 48 );
+			memcpy( &cu[8 * (size_t)i + 3], d->cube_b + 8 * (size_t)i, 32 );
+			memcpy( &cu[8 * (size_t)i + 5], d->cube_M + 16 * (size_t)i, 48 );
+		}
+		const int planeBase = d->n_quads + d->n_spheres + d->n_cubes;
+		for (int i = 0; i < d->n_planes; i++) memcpy( &pl[i], d->primitives + 4 * (size_t)( planeBase + i ), 16 );
+		float4* a = 0, *b = 0, *p = 0;
+		if (( r = dev_upload( c, &a, q.data(), q.size(), &allocs ) ) || ( r = dev_upload( c, &b, cu.data(), cu.size(), &allocs ) ) || ( r = dev_upload( c, &p, pl.data(), pl.size(), &allocs ) )) return bail( r );
+		ds.quads = a, ds.cubes = b, ds.planes = p;
+	}
+	// shading data: per-primitive materials deduplicated into a table (the reference assigns one Material per object / OBJ file)
+	{
+		std::vector<DMaterial> table;
+		std::vector<uint8_t> ids( (size_t)std::max<long long>( total, 1 ) );
+		for (long long i = 0; i < total; i++)
+		{
+			DMaterial m = {};
+			memcpy( &m.color, d->albedo + 4 * i, 16 ), memcpy( &m.absorption, d->absorption + 4 * i, 16 );
+			m.ior = d->ior[i], m.type = d->material_type[i];
+			if (m.type < 0 || m.type > 4) return bail( fail( c, RTMI_ERR_INVALID, "material_type out of range" ) );
+			int found = -1;
+			for (int k = (int)table.size() - 1; k >= 0; k--) if (memcmp( &table[k], &m, sizeof( DMaterial ) ) == 0) { found = k; break; }
+			if (found < 0)
+			{
+				if (table.size() >= 255) return bail( fail( c, RTMI_ERR_INVALID, "more than 255 distinct materials" ) );
+				found = (int)table.size(), table.push_back( m );
+			}
+			ids[i] = (uint8_t)found;
+		}
+		if (table.empty()) table.push_back( DMaterial{} );
+		float4* prim = 0; uint8_t* mid = 0; DMaterial* mt = 0; float* invr = 0; uint32_t* tex = 0;
+		if (( r = dev_upload( c, &prim, (const float4*)d->primitives, (size_t)total, &allocs ) ) || ( r = dev_upload( c, &mid, ids.data(), ids.size(), &allocs ) ) ||
+			( r = dev_upload( c, &mt, table.data(), table.size(), &allocs ) ) || ( r = dev_upload( c, &invr, d->sphere_invr, (size_t)d->n_spheres, &allocs ) )) return bail( r );
+		if (d->texture) { if (( r = dev_upload( c, &tex, d->texture, (size_t)d->tex_w * d->tex_h, &allocs ) )) return bail( r ); }
+		ds.primitives = prim, ds.mat_id = mid, ds.materials = mt, ds.sphere_invr = invr, ds.texture = tex, ds.tex_w = d->tex_w, ds.tex_h = d->tex_h;
+	}
+	memcpy( &ds.light_c1, d->light_corners, 16 ), memcpy( &ds.light_c2, d->light_corners + 4, 16 ), memcpy( &ds.light_c3, d->light_corners + 8, 16 );
+	memcpy( &ds.light_emission, d->light_emission, 16 );
+	if (d->n_quads > 0) memcpy( &ds.light_N, d->primitives, 16 ); // quads[0].N, scene.h:120 / 323
+	ds.light_A = d->light_A, ds.light_s = d->light_s;
+	memcpy( ds.wl_pos, d->whitted_light_pos, 32 ), memcpy( ds.wl_color, d->whitted_light_color, 32 );
+	ds.wl_intensity = d->whitted_intensity;
+
+	free_scene( c );
+	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
+	c->stack_depth = std::max( 4, maxDepth + 1 );
+	return RTMI_OK;
+}
+
+int rtmi_set_camera( rtmi_ctx* c, const float cam[16] )
+{
+	if (!c || !cam) return RTMI_ERR_INVALID;
+	memcpy( &c->cam, cam, 64 );
+	return RTMI_OK;
+}
+int rtmi_set_seeds( rtmi_ctx* c, const uint32_t* seeds )
+{
+	if (!c || !seeds) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipMemcpyAsync( c->seeds, seeds, (size_t)c->W * c->H * 4, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	return RTMI_OK;
+}
+int rtmi_reset_accumulator( rtmi_ctx* c )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipMemsetAsync( c->accum, 0, (size_t)c->W * c->H * sizeof( float4 ), c->stream ) );
+	return RTMI_OK;
+}
+int rtmi_set_accumulator( rtmi_ctx* c, void* p )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	c->accum = p ? (float4*)p : c->accum_own;
+	return RTMI_OK;
+}
+
+static size_t stack_bytes( rtmi_ctx* c ) { return (size_t)c->stack_depth * BLOCK * sizeof( uint32_t ); }
+
+// one batch of S samples: bounce 0 over all S*W*H slots, then queue-driven bounces until the queue is empty
+static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
+{
+	const int WH = c->W * c->H;
+	const uint32_t N = (uint32_t)( (size_t)S * WH );
+	const float invW = 1.0f / c->W, invH = 1.0f / c->H; // camera.h:31-32
+	const size_t lds = stack_bytes( c );
+	hipStream_t s = c->stream;
+	HIPCHK( hipMemsetAsync( c->ctr, 0, 16, s ) ); // next[2], shadow, pad
+	const bool cn = c->count_nodes;
+	{
+		ScopedTimer t( c, 0 );
+		if (cn) hipLaunchKernelGGL( ( k_extend<true, true> ), dim3( nblocks( N ) ), dim3( BLOCK ), lds, s, c->ds, c->st, nullptr, nullptr, N, c->cam, c->W, c->H, invW, invH, c->ctr );
+		else hipLaunchKernelGGL( ( k_extend<true, false> ), dim3( nblocks( N ) ), dim3( BLOCK ), lds, s, c->ds, c->st, nullptr, nullptr, N, c->cam, c->W, c->H, invW, invH, c->ctr );
+	}
+	{
+		ScopedTimer t( c, 1 );
+		hipLaunchKernelGGL( ( k_shade<true> ), dim3( nblocks( N ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, nullptr, c->queue[0], nullptr, N, c->seeds, WH, sample_begin, stride,
+			&c->ctr->next[0], &c->ctr->shadow );
+	}
+	c->stats.primary_samples += N;
+	uint32_t upper = N; // upper bound of the current bounce queue length (lengths never grow)
+	int cur = 0;        // queue[cur] / next[cur] feed the next extend
+	for (int bounce = 0;; bounce++)
+	{
+		// connect for this bounce's shadow rays (at most `upper` of them)
+		{
+			ScopedTimer t( c, 2 );
+			if (cn) hipLaunchKernelGGL( ( k_connect<true> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
+			else hipLaunchKernelGGL( ( k_connect<false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
+		}
+		c->stats.bounce_launches++;
+		// read back the length of the queue that feeds bounce+1, two iterations late
+		const int slot = bounce & 3;
+		HIPCHK( hipMemcpyAsync( &c->host_counts[slot], &c->ctr->next[cur], 4, hipMemcpyDeviceToHost, s ) );
+		HIPCHK( hipEventRecord( c->count_ev[slot], s ) );
+		if (bounce >= 2)
+		{
+			const int old = ( bounce - 2 ) & 3;
+			HIPCHK( hipEventSynchronize( c->count_ev[old] ) );
+			upper = std::min( upper, c->host_counts[old] );
+		}
+		if (upper == 0) break;
+		hipLaunchKernelGGL( k_reset_shadow, dim3( 1 ), dim3( 1 ), 0, s, c->ctr, cur ^ 1 );
+		{
+			ScopedTimer t( c, 0 );
+			if (cn) hipLaunchKernelGGL( ( k_extend<false, true> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->queue[cur], &c->ctr->next[cur], 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
+			else hipLaunchKernelGGL( ( k_extend<false, false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->queue[cur], &c->ctr->next[cur], 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
+		}
+		{
+			ScopedTimer t( c, 1 );
+			hipLaunchKernelGGL( ( k_shade<false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, c->queue[cur], c->queue[cur ^ 1], &c->ctr->next[cur], 0u, c->seeds, WH,
+				sample_begin, stride, &c->ctr->next[cur ^ 1], &c->ctr->shadow );
+		}
+		cur ^= 1;
+	}
+	{
+		ScopedTimer t( c, 3 );
+		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, s, c->accum, c->st.E_f, WH, S );
+	}
+	HIPCHK( hipGetLastError() );
+	return RTMI_OK;
+}
+
+static int fetch_counters( rtmi_ctx* c )
+{
+	DevCounters h;
+	HIPCHK( hipMemcpyAsync( &h, c->ctr, sizeof( h ), hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
+	c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
+	c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
+	HIPCHK( hipMemsetAsync( c->ctr, 0, sizeof( DevCounters ), c->stream ) );
+	return RTMI_OK;
+}
+
+int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int sample_stride, int max_depth, int anti_aliasing )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_render before rtmi_upload_scene" );
+	HIPCHK( hipSetDevice( c->device ) );
+	const int WH = c->W * c->H;
+	if (mode == RTMI_PATHTRACING)
+	{
+		if (sample_count <= 0 || sample_stride <= 0 || sample_begin < 0) return fail( c, RTMI_ERR_INVALID, "bad sample range" );
+		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
+		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 23 ) / WH ) );
+		const char* env = getenv( "RTMI_BATCH" );
+		if (env && atoi( env ) > 0) S = std::min( sample_count, atoi( env ) );
+		int r = ensure_batch( c, S );
+		if (r) return r;
+		for (int done = 0; done < sample_count; done += S)
+		{
+			const int n = std::min( S, sample_count - done );
+			if (( r = render_batch( c, sample_begin + done * sample_stride, n, sample_stride ) )) return r;
+		}
+		// counters are folded into the stats lazily (rtmi_get_stats), no sync here
+		return RTMI_OK;
+	}
+	if (mode < 0 || mode > RTMI_PATHTRACING) return fail( c, RTMI_ERR_INVALID, "unknown mode" );
+	if (max_depth < 1 || max_depth > 64) return fail( c, RTMI_ERR_INVALID, "max_depth must be 1..64" );
+	if (c->frames_depth < max_depth)
+	{
+		if (c->frames) (void)hipFree( c->frames ), c->frames = 0;
+		int r = dev_alloc( c, &c->frames, (size_t)WH * ( max_depth + 1 ) );
+		if (r) return r;
+		c->frames_depth = max_depth;
+	}
+	{
+		ScopedTimer t( c, 3 );
+		hipLaunchKernelGGL( k_whitted, dim3( nblocks( WH ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, mode, max_depth,
+			anti_aliasing, c->frames, c->accum );
+	}
+	HIPCHK( hipGetLastError() );
+	return RTMI_OK;
+}
+
+int rtmi_trace_primary( rtmi_ctx* c, int32_t* obj_out, float* t_out )
+{
+	if (!c || !obj_out || !t_out) return RTMI_ERR_INVALID;
+	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_trace_primary before rtmi_upload_scene" );
+	HIPCHK( hipSetDevice( c->device ) );
+	int r = ensure_batch( c, 1 );
+	if (r) return r;
+	const int WH = c->W * c->H;
+	int* dobj = 0; float* dt = 0;
+	if (( r = dev_alloc( c, &dobj, WH ) )) return r;
+	if (( r = dev_alloc( c, &dt, WH ) )) { (void)hipFree( dobj ); return r; }
+	hipLaunchKernelGGL( ( k_extend<true, false> ), dim3( nblocks( WH ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, c->st, nullptr, nullptr, (uint32_t)WH, c->cam, c->W, c->H,
+		1.0f / c->W, 1.0f / c->H, c->ctr );
+	hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, c->stream, c->st, WH, dobj, dt );
+	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e3 = hipStreamSynchronize( c->stream );
+	(void)hipFree( dobj ), (void)hipFree( dt );
+	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
+	return RTMI_OK;
+}
+
+int rtmi_trace_rays( rtmi_ctx* c, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* obj_out, float* t_out )
+{
+	if (!c || n < 0 || ( n && ( !O3 || !D3 || !tmax || !obj_out || !t_out ) )) return RTMI_ERR_INVALID;
+	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_trace_rays before rtmi_upload_scene" );
+	if (n == 0) return RTMI_OK;
+	HIPCHK( hipSetDevice( c->device ) );
+	std::vector<void*> tmp;
+	float* dO = 0, *dD = 0, *dT = 0, *dt = 0; int* dobj = 0;
+	int r;
+	auto cleanup = [&]() { for (void* p : tmp) (void)hipFree( p ); };
+	if (( r = dev_upload( c, &dO, O3, (size_t)n * 3, &tmp ) ) || ( r = dev_upload( c, &dD, D3, (size_t)n * 3, &tmp ) ) || ( r = dev_upload( c, &dT, tmax, (size_t)n, &tmp ) ) ||
+		( r = dev_alloc( c, &dt, (size_t)n, &tmp ) ) || ( r = dev_alloc( c, &dobj, (size_t)n, &tmp ) )) { cleanup(); return r; }
+	hipLaunchKernelGGL( k_trace_rays, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e3 = hipStreamSynchronize( c->stream );
+	cleanup();
+	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
+	return RTMI_OK;
+}
+
+static int run_postfx( rtmi_ctx* c, uint32_t* px, uint32_t* tmp, int W, int H, const rtmi_postfx* fx )
+{
+	const int n = W * H;
+	if (fx->gamma_on)
+	{
+		// GammaCorrection, postprocessing.h:78-99
+		uint32_t lut[256];
+		const float gc = 1.0f / fx->gamma;
+		for (int i = 0; i < 256; i++) lut[i] = (uint32_t)( 255.0f * powf( (float)i / 255.0f, gc ) ) & 255u;
+		HIPCHK( hipMemcpyAsync( c->gamma_lut, lut, sizeof( lut ), hipMemcpyHostToDevice, c->stream ) );
+		HIPCHK( hipStreamSynchronize( c->stream ) ); // lut is on the stack
+		hipLaunchKernelGGL( k_gamma, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, px, n, c->gamma_lut );
+	}
+	if (fx->chroma_on)
+	{
+		hipLaunchKernelGGL( k_chroma, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, px, tmp, W, H, fx->chroma_intensity );
+		HIPCHK( hipMemcpyAsync( px, tmp, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream ) ); // postprocessing.h:75
+	}
+	if (fx->vignette_on) hipLaunchKernelGGL( k_vignette, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, px, W, H, fx->vignette_intensity );
+	HIPCHK( hipGetLastError() );
+	return RTMI_OK;
+}
+
+int rtmi_finalize( rtmi_ctx* c, uint32_t* out, int frames, const rtmi_postfx* fx )
+{
+	if (!c || !out) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	const int n = c->W * c->H;
+	{
+		ScopedTimer t( c, 3 );
+		hipLaunchKernelGGL( k_finalize, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->pixels, n, frames );
+	}
+	if (fx) { int r = run_postfx( c, c->pixels, c->pixels2, c->W, c->H, fx ); if (r) return r; }
+	HIPCHK( hipMemcpyAsync( out, c->pixels, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	return RTMI_OK;
+}
+
+int rtmi_postprocess( rtmi_ctx* c, uint32_t* px, int W, int H, const rtmi_postfx* fx )
+{
+	if (!c || !px || !fx || W <= 0 || H <= 0) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	const size_t n = (size_t)W * H;
+	uint32_t* a = 0, *b = 0;
+	int r;
+	if (( r = dev_alloc( c, &a, n ) )) return r;
+	if (( r = dev_alloc( c, &b, n ) )) { (void)hipFree( a ); return r; }
+	hipError_t e = hipMemcpyAsync( a, px, n * 4, hipMemcpyHostToDevice, c->stream );
+	if (e == hipSuccess) r = run_postfx( c, a, b, W, H, fx );
+	if (e == hipSuccess && !r) e = hipMemcpyAsync( px, a, n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e2 = hipStreamSynchronize( c->stream );
+	(void)hipFree( a ), (void)hipFree( b );
+	if (r) return r;
+	HIPCHK( e ); HIPCHK( e2 );
+	return RTMI_OK;
+}
+
+int rtmi_read_accumulator( rtmi_ctx* c, float* out )
+{
+	if (!c || !out) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipMemcpyAsync( out, c->accum, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	return RTMI_OK;
+}
+
+int rtmi_set_profiling( rtmi_ctx* c, int ev, int cn )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	c->prof_events = ev != 0, c->count_nodes = cn != 0;
+	return RTMI_OK;
+}
+int rtmi_get_stats( rtmi_ctx* c, rtmi_stats* out )
+{
+	if (!c || !out) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	int r = fetch_counters( c );
+	if (r) return r;
+	resolve_timers( c );
+	*out = c->stats;
+	return RTMI_OK;
+}
+int rtmi_reset_stats( rtmi_ctx* c )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	int r = fetch_counters( c );
+	if (r) return r;
+	resolve_timers( c );
+	c->stats = rtmi_stats{};
+	return RTMI_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,118 @@
+// capi.cpp -- plain-C handles over the C++ host mirror (Scene, BVH, Camera, Renderer) for the Python harness
+// (tests/, bench.py, __graft_entry__.py) via ctypes.  No arithmetic of its own.
+#include "renderer.h"
+#include <cstdio>
+
+using namespace rtmi;
+
+extern "C" {
+
+struct rth_material { int type; float color[3]; float ior; float absorption[3]; float emission[3]; };
+
+static Material to_mat( const rth_material* m )
+{
+	return Material( (Material::MaterialType)m->type, float3( m->color[0], m->color[1], m->color[2] ), 0, m->ior,
+		float3( m->absorption[0], m->absorption[1], m->absorption[2] ), float3( m->emission[0], m->emission[1], m->emission[2] ) );
+}
+
+void* rth_scene_create() { return new Scene(); }
+void rth_scene_destroy( void* s ) { delete (Scene*)s; }
+int rth_scene_make_default( void* s, const char* assets, int builder ) { return ( (Scene*)s )->MakeDefault( assets, (BVH::Builder)builder ) ? 0 : -1; }
+void rth_scene_make_room( void* s ) { ( (Scene*)s )->MakeRoom(); }
+void rth_scene_add_sphere( void* s, float x, float y, float z, float r, const rth_material* m ) { ( (Scene*)s )->AddSphere( float3( x, y, z ), r, to_mat( m ) ); }
+void rth_scene_add_triangles( void* s, const float* v9, long long n, const rth_material* m, float ox, float oy, float oz )
+{
+	( (Scene*)s )->AddTriangles( v9, (size_t)n, to_mat( m ), float3( ox, oy, oz ) );
+}
+void rth_scene_add_torus_knot( void* s, int nu, int nv, float R, float r, float tube, int p, int q, float cx, float cy, float cz, const rth_material* m )
+{
+	std::vector<float> v;
+	MakeTorusKnot( nu, nv, R, r, tube, p, q, float3( cx, cy, cz ), v );
+	( (Scene*)s )->AddTriangles( v.data(), v.size() / 9, to_mat( m ) );
+}
+int rth_scene_load_obj( void* s, const char* path, const rth_material* m, float ox, float oy, float oz )
+{
+	return ( (Scene*)s )->LoadObject( path, to_mat( m ), float3( ox, oy, oz ) ) ? 0 : -1;
+}
+int rth_scene_load_texture_raw( void* s, const char* path, int w, int h ) { return ( (Scene*)s )->LoadTextureRaw( path, w, h ) ? 0 : -1; }
+void rth_scene_finalize( void* s, int builder ) { ( (Scene*)s )->Finalize( (BVH::Builder)builder ); }
+const rtmi_scene_desc* rth_scene_desc( void* s ) { return ( (Scene*)s )->Desc(); }
+void rth_scene_info( void* s, int* out )
+{
+	Scene* sc = (Scene*)s;
+	out[0] = sc->quads_size, out[1] = sc->spheres_size, out[2] = sc->cubes_size, out[3] = sc->planes_size, out[4] = sc->triangles_size;
+	out[5] = sc->bvh ? (int)sc->bvh->nodesUsed : 0, out[6] = sc->bvh ? sc->bvh->maxDepth : 0;
+}
+void rth_quad_T( void* s, float* T16 ) { memcpy( T16, ( (Scene*)s )->quads[0].T.cell, 64 ); }
+
+void rth_fill_seeds( uint32_t* out, long long n ) { FillSeedTable( out, (size_t)n ); }
+void rth_camera_default( int w, int h, float* cam16 ) { Camera c( w, h ); memcpy( cam16, c.gpuCamProp, 64 ); }
+void rth_camera_primary_rays( int w, int h, float* O3, float* D3, float* rD3 )
+{
+	Camera c( w, h );
+	for (int y = 0; y < h; y++) for (int x = 0; x < w; x++)
+	{
+		Ray r = c.GetPrimaryRay( x, y );
+		const size_t p = (size_t)x + (size_t)y * w;
+		memcpy( O3 + 3 * p, &r.O, 12 ), memcpy( D3 + 3 * p, &r.D, 12 ), memcpy( rD3 + 3 * p, &r.rD, 12 );
+	}
+}
+
+// standalone BVH build over caller triangles (9 floats) and spheres (pos, r); nodes_out has room for 2*(nt+ns)+1 nodes
+int rth_bvh_build( const float* v9, int nt, const float* pr4, int ns, int builder, rtmi_bvh_node* nodes_out, int* prim_idx_out, int* info )
+{
+	std::vector<Triangle> tris( nt );
+	std::vector<Sphere> sph( ns );
+	Material m;
+	for (int i = 0; i < ns; i++) sph[i] = Sphere( i, float3( pr4[4 * i], pr4[4 * i + 1], pr4[4 * i + 2] ), pr4[4 * i + 3], m );
+	for (int i = 0; i < nt; i++)
+	{
+		const float* v = v9 + 9 * (size_t)i;
+		tris[i] = Triangle( ns + i, float3( v[0], v[1], v[2] ), float3( v[3], v[4], v[5] ), float3( v[6], v[7], v[8] ), m );
+	}
+	BVH bvh( sph.data(), ns, 0, 0, tris.data(), nt, (BVH::Builder)builder );
+	memcpy( nodes_out, bvh.gpuBvhNode, sizeof( GPUBVHNode ) * bvh.nodesUsed );
+	memcpy( prim_idx_out, bvh.primitiveIdx, sizeof( int ) * ( nt + ns ) );
+	info[0] = (int)bvh.nodesUsed, info[1] = bvh.maxDepth;
+	return 0;
+}
+void rth_triangle_derived( const float* v9, int n, float* N3, float* centroid3 )
+{
+	Material m;
+	for (int i = 0; i < n; i++)
+	{
+		const float* v = v9 + 9 * (size_t)i;
+		Triangle t( 0, float3( v[0], v[1], v[2] ), float3( v[3], v[4], v[5] ), float3( v[6], v[7], v[8] ), m );
+		memcpy( N3 + 3 * i, &t.N, 12 ), memcpy( centroid3 + 3 * i, &t.centroid, 12 );
+	}
+}
+long long rth_torus_knot( int nu, int nv, float R, float r, float tube, int p, int q, float cx, float cy, float cz, float* v9_out )
+{
+	std::vector<float> v;
+	MakeTorusKnot( nu, nv, R, r, tube, p, q, float3( cx, cy, cz ), v );
+	if (v9_out) memcpy( v9_out, v.data(), v.size() * 4 );
+	return (long long)( v.size() / 9 );
+}
+int rth_write_obj( const char* path, const float* v9, long long n ) { return WriteObj( path, v9, (size_t)n ) ? 0 : -1; }
+
+// ---- Renderer ------------------------------------------------------------------------------------------------
+void* rth_renderer_create( int w, int h, int device ) { return new Renderer( w, h, device ); }
+void rth_renderer_destroy( void* r ) { delete (Renderer*)r; }
+void* rth_renderer_scene( void* r ) { return &( (Renderer*)r )->scene; }
+int rth_renderer_init( void* r ) { return ( (Renderer*)r )->Init() ? 0 : -1; }
+int rth_renderer_upload_scene( void* r ) { return ( (Renderer*)r )->UploadScene() ? 0 : -1; }
+void rth_renderer_tick( void* r, float dt ) { ( (Renderer*)r )->Tick( dt ); }
+void rth_renderer_set_mode( void* r, int mode ) { ( (Renderer*)r )->SetVisualizationMode( (Renderer::VisualizationMode)mode ); }
+void rth_renderer_set_aa( void* r, int aa ) { ( (Renderer*)r )->SetAntiAliasing( aa != 0 ); }
+void rth_renderer_set_depth( void* r, int d ) { ( (Renderer*)r )->SetRecusionDepth( d ); }
+void rth_renderer_set_spp_per_tick( void* r, int n ) { ( (Renderer*)r )->samplesPerTick = n > 0 ? n : 1; }
+void rth_renderer_set_postfx( void* r, const rtmi_postfx* fx, int on ) { ( (Renderer*)r )->SetPostFx( *fx, on != 0 ); }
+void rth_renderer_key( void* r, int key, int down ) { if (down) ( (Renderer*)r )->KeyDown( key ); else ( (Renderer*)r )->KeyUp( key ); }
+unsigned rth_renderer_frames( void* r ) { return ( (Renderer*)r )->accumulatedFrames; }
+const uint32_t* rth_renderer_pixels( void* r ) { return ( (Renderer*)r )->screenPixels; }
+const float* rth_renderer_accumulator( void* r ) { Renderer* R = (Renderer*)r; return R->ReadAccumulator() ? &R->accumulator[0].x : 0; }
+void* rth_renderer_ctx( void* r ) { return ( (Renderer*)r )->ctx; }
+const char* rth_renderer_error( void* r ) { return ( (Renderer*)r )->LastError(); }
+float rth_renderer_last_ms( void* r ) { return ( (Renderer*)r )->lastFrameMs; }
+
+} // extern "C"

@@ -1,0 +1,301 @@
+// scene.cpp -- host scene container (see scene.h).  Build with -O2 -ffp-contract=off.
+#include "scene.h"
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+
+namespace rtmi {
+
+Scene::~Scene() { delete bvh; }
+
+void Scene::InitMaterials() // scene.h:42-48
+{
+	def_mat = Material( Material::MaterialType::DIFFUSE, float3( 0.93f ), 0 );
+	red_mat = Material( Material::MaterialType::DIFFUSE, float3( 0.93f, 0.21f, 0.21f ), 0 );
+	cyan_mat = Material( Material::MaterialType::DIFFUSE, float3( 0.11f, 0.95f, 0.91f ), 0 );
+	mirror_mat = Material( Material::MaterialType::MIRROR, float3( 0.93f ), 0 );
+	absorb_all_but_blue_mat = Material( Material::MaterialType::GLASS, float3( 1 ), 0, 1.52, float3( 8.0f, 2.0f, 1.0f ) );
+	glass_mat = Material( Material::MaterialType::GLASS, float3( 0.93f ), 0, 1.52, float3( 0 ) );
+	light_mat = Material( Material::MaterialType::LIGHT, float3( 0.93f ), 0, 0, float3( 0 ), float3( 2.0f ) );
+}
+
+void Scene::AddQuad( float s, const Material& m, const mat4& T ) { vq.push_back( Quad( 0, s, m, T ) ); }
+void Scene::AddSphere( float3 p, float r, const Material& m ) { vs.push_back( Sphere( 0, p, r, m ) ); }
+void Scene::AddCube( float3 pos, float3 size, const Material& m, const mat4& T ) { vc.push_back( Cube( 0, pos, size, m, T ) ); }
+void Scene::AddPlane( float3 N, float d, const Material& m ) { vp.push_back( Plane( 0, N, d, m ) ); }
+void Scene::AddTriangles( const float* v, size_t count, const Material& m, float3 off )
+{
+	vt.reserve( vt.size() + count );
+	for (size_t i = 0; i < count; i++, v += 9)
+		vt.push_back( Triangle( 0, float3( v[0], v[1], v[2] ) + off, float3( v[3], v[4], v[5] ) + off, float3( v[6], v[7], v[8] ) + off, m ) );
+}
+
+void Scene::MakeRoom()
+{
+	InitMaterials();
+	// scene.h:51-52, 58: light quad; scene.h:70-75: the six walls
+	mat4 M1base = mat4::Translate( float3( 0, 2.6f, 2 ) );
+	mat4 M1 = M1base * mat4::RotateZ( sinf( 0 * 0.6f ) * 0.1f ) * mat4::Translate( float3( 0, -0.9, 0 ) );
+	AddQuad( 3, light_mat, M1 );
+	AddPlane( float3( 1, 0, 0 ), 3, mirror_mat );
+	AddPlane( float3( -1, 0, 0 ), 2.99f, def_mat );
+	AddPlane( float3( 0, 1, 0 ), 1, def_mat );
+	AddPlane( float3( 0, -1, 0 ), 2, def_mat );
+	AddPlane( float3( 0, 0, 1 ), 3, def_mat );
+	AddPlane( float3( 0, 0, -1 ), 3.99f, def_mat );
+}
+
+bool Scene::MakeDefault( const std::string& assets, BVH::Builder builder )
+{
+	MakeRoom();
+	// scene.h:61-63
+	AddSphere( float3( -1.4f, -0.5f, 2 ), 0.5f, absorb_all_but_blue_mat );
+	AddSphere( float3( 0, 2.5f, -3.07f ), 0.5f, def_mat );
+	// scene.h:54-55, 66
+	mat4 M2base = mat4::RotateX( PI / 4 ) * mat4::RotateZ( PI / 4 );
+	mat4 M2 = mat4::Translate( float3( 1.4f, 0, 2 ) ) * mat4::RotateY( 0 * 0.5f ) * M2base;
+	AddCube( float3( 0 ), float3( 0.75f ), def_mat, M2 );
+	// scene.h:80-82
+	if (!LoadObject( assets + "/monkey.obj", glass_mat, float3( 0, 0, 1.5 ) )) return false;
+	if (!LoadObject( assets + "/monkey.obj", cyan_mat, float3( 1.5, 0, 1.5 ) )) return false;
+	if (!LoadObject( assets + "/monkey.obj", red_mat, float3( -1.5, 0, 1.5 ) )) return false;
+	if (!LoadTextureRaw( assets + "/logo_128x64.rgb32", 128, 64 )) return false;
+	Finalize( builder );
+	return true;
+}
+
+void Scene::SetTexture( const uint32_t* px, int w, int h ) { texture.assign( px, px + (size_t)w * h ), tex_w = w, tex_h = h; }
+bool Scene::LoadTextureRaw( const std::string& file, int w, int h )
+{
+	std::ifstream f( file, std::ios::binary );
+	if (!f) return false;
+	texture.resize( (size_t)w * h );
+	f.read( (char*)texture.data(), (std::streamsize)texture.size() * 4 );
+	tex_w = w, tex_h = h;
+	return (size_t)f.gcount() == texture.size() * 4;
+}
+
+// Decimal text -> double the way tinyobjloader v2.0.0 does it (tiny_obj_loader.h:887-1017, the parser the
+// reference's LoadObject goes through): digits are accumulated into a double mantissa, fractional digits are
+// added as digit * 10^-k from a small table, and a decimal exponent is applied as ldexp(m * 5^e, e).  Restated
+// (not strtod) so that vertices come out bit-identical to the reference's.
+static bool ParseReal( const char*& s, float& out )
+{
+	while (*s == ' ' || *s == '\t') s++;
+	const char* c = s;
+	double m = 0.0;
+	int exponent = 0, read = 0;
+	char sign = '+', esign = '+';
+	bool leadingDot = false;
+	if (*c == '+' || *c == '-') { sign = *c++; if (*c == '.') leadingDot = true; }
+	else if (*c >= '0' && *c <= '9') {}
+	else if (*c == '.') leadingDot = true;
+	else return false;
+	if (!leadingDot)
+	{
+		while (*c >= '0' && *c <= '9') m *= 10, m += (int)( *c - '0' ), c++, read++;
+		if (read == 0) return false;
+	}
+	if (*c == '.')
+	{
+		static const double lut[] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
+		c++, read = 1;
+		while (*c >= '0' && *c <= '9') m += (int)( *c - '0' ) * ( read < 8 ? lut[read] : std::pow( 10.0, -read ) ), read++, c++;
+	}
+	if (*c == 'e' || *c == 'E')
+	{
+		c++;
+		if (*c == '+' || *c == '-') esign = *c++;
+		else if (!( *c >= '0' && *c <= '9' )) return false;
+		read = 0;
+		while (*c >= '0' && *c <= '9') { if (exponent > 214748364) return false; exponent = exponent * 10 + ( *c - '0' ), c++, read++; }
+		exponent *= ( esign == '+' ? 1 : -1 );
+		if (read == 0) return false;
+	}
+	const double r = ( sign == '+' ? 1 : -1 ) * ( exponent ? std::ldexp( m * std::pow( 5.0, exponent ), exponent ) : m );
+	out = (float)r;
+	s = c;
+	return true;
+}
+
+bool Scene::LoadObject( const std::string& file, const Material& material, float3 transform )
+{
+	std::ifstream f( file );
+	if (!f) { fprintf( stderr, "rtmi::Scene::LoadObject: cannot open %s\n", file.c_str() ); return false; }
+	std::vector<float> v; // xyz
+	std::string line;
+	size_t before = vt.size();
+	while (std::getline( f, line ))
+	{
+		const char* s = line.c_str();
+		while (*s == ' ' || *s == '\t') s++;
+		if (s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' ))
+		{
+			s += 2;
+			float x = 0, y = 0, z = 0;
+			ParseReal( s, x ), ParseReal( s, y ), ParseReal( s, z );
+			v.push_back( x ), v.push_back( y ), v.push_back( z );
+		}
+		else if (s[0] == 'f' && ( s[1] == ' ' || s[1] == '\t' ))
+		{
+			s += 2;
+			std::vector<int> idx;
+			while (*s)
+			{
+				while (*s == ' ' || *s == '\t' || *s == '\r') s++;
+				if (!*s) break;
+				char* end;
+				long i = strtol( s, &end, 10 );
+				if (end == s) break;
+				const int nv = (int)( v.size() / 3 );
+				idx.push_back( i > 0 ? (int)i - 1 : nv + (int)i ); // 1-based, negative = relative to the end
+				s = end;
+				while (*s && *s != ' ' && *s != '\t') s++; // skip /vt/vn
+			}
+			// faces with more than 3 corners are fanned (the reference's assets are all triangles)
+			for (size_t k = 2; k < idx.size(); k++)
+			{
+				const int a = idx[0], b = idx[k - 1], c = idx[k];
+				if (a < 0 || b < 0 || c < 0 || (size_t)a * 3 + 2 >= v.size() || (size_t)b * 3 + 2 >= v.size() || (size_t)c * 3 + 2 >= v.size()) return false;
+				const float3 vx( v[3 * a], v[3 * a + 1], v[3 * a + 2] ), vy( v[3 * b], v[3 * b + 1], v[3 * b + 2] ), vz( v[3 * c], v[3 * c + 1], v[3 * c + 2] );
+				vt.push_back( Triangle( 0, vx + transform, vy + transform, vz + transform, material ) ); // scene.h:266
+			}
+		}
+	}
+	return vt.size() > before;
+}
+
+void Scene::Finalize( BVH::Builder builder )
+{
+	quads = vq.data(), quads_size = (int)vq.size();
+	spheres = vs.data(), spheres_size = (int)vs.size();
+	cubes = vc.data(), cubes_size = (int)vc.size();
+	planes = vp.data(), planes_size = (int)vp.size();
+	triangles = vt.data(), triangles_size = (int)vt.size();
+	// global object indices in class order (scene.h:58-75, 266-270)
+	id = 0;
+	for (auto& q : vq) q.objIdx = id++;
+	for (auto& s : vs) s.objIdx = id++;
+	for (auto& c : vc) c.objIdx = id++;
+	for (auto& p : vp) p.objIdx = id++;
+	for (auto& t : vt) t.objIdx = id++;
+	delete bvh;
+	bvh = new BVH( spheres, spheres_size, planes, planes_size, triangles, triangles_size, builder );
+
+	const int total = TotalPrimitives();
+	albedos.assign( total, float4( 0 ) ), absorptions.assign( total, float4( 0 ) ), primitives.assign( total, float4( 0 ) );
+	primMaterials.assign( total, 0 ), refractiveIndices.assign( total, 0 );
+	quadMatrices.resize( quads_size ), quadSizes.resize( quads_size );
+	sphereInfos.resize( spheres_size ), sphereInvrs.resize( spheres_size );
+	cubeMatrices.resize( cubes_size ), cubeInvMatrices.resize( cubes_size ), cubeBs.resize( (size_t)cubes_size * 2 );
+	triangleInfos.resize( (size_t)triangles_size * 3 );
+	int i = 0;
+	auto mat = [&]( int k, const Material& m ) {
+		primMaterials[k] = (int)m.type, albedos[k] = float4( m.color, 0 );
+		refractiveIndices[k] = m.refractive_index, absorptions[k] = float4( m.absorption, 0 ); };
+	for (int k = 0; k < quads_size; k++, i++) // scene.h:116-124
+		mat( i, quads[k].material ), quadMatrices[k] = quads[k].invT, quadSizes[k] = quads[k].size, primitives[i] = float4( quads[k].N, 0 );
+	for (int k = 0; k < spheres_size; k++, i++) // scene.h:131-139
+		mat( i, spheres[k].material ), sphereInfos[k] = float4( spheres[k].pos, spheres[k].r2 ), primitives[i] = float4( spheres[k].pos, 0 ), sphereInvrs[k] = spheres[k].invr;
+	for (int k = 0; k < cubes_size; k++, i++) // scene.h:147-157
+		mat( i, cubes[k].material ), cubeInvMatrices[k] = cubes[k].invM, cubeMatrices[k] = cubes[k].M,
+		cubeBs[2 * k] = float4( cubes[k].b[0], 0 ), cubeBs[2 * k + 1] = float4( cubes[k].b[1], 0 ), primitives[i] = float4( 0 );
+	for (int k = 0; k < planes_size; k++, i++) // scene.h:165-171
+		mat( i, planes[k].material ), primitives[i] = float4( planes[k].N, planes[k].d );
+	for (int k = 0; k < triangles_size; k++, i++) // scene.h:176-185
+	{
+		mat( i, triangles[k].material );
+		triangleInfos[3 * (size_t)k] = float4( triangles[k].pos1, 0.0f ), triangleInfos[3 * (size_t)k + 1] = float4( triangles[k].pos2, 0.0f );
+		triangleInfos[3 * (size_t)k + 2] = float4( triangles[k].pos3, 0.0f ), primitives[i] = float4( triangles[k].N, 0 );
+	}
+
+	desc = rtmi_scene_desc{};
+	desc.n_quads = quads_size, desc.n_spheres = spheres_size, desc.n_cubes = cubes_size, desc.n_planes = planes_size, desc.n_triangles = triangles_size;
+	desc.quad_inv_T = quads_size ? quadMatrices[0].cell : 0, desc.quad_size = quadSizes.data();
+	desc.sphere_info = (const float*)sphereInfos.data(), desc.sphere_invr = sphereInvrs.data();
+	desc.cube_M = cubes_size ? cubeMatrices[0].cell : 0, desc.cube_inv_M = cubes_size ? cubeInvMatrices[0].cell : 0, desc.cube_b = (const float*)cubeBs.data();
+	desc.tri_verts = (const float*)triangleInfos.data();
+	desc.primitives = (const float*)primitives.data(), desc.albedo = (const float*)albedos.data();
+	desc.material_type = primMaterials.data(), desc.ior = refractiveIndices.data(), desc.absorption = (const float*)absorptions.data();
+	desc.nodes = (const rtmi_bvh_node*)bvh->gpuBvhNode, desc.n_nodes = (int)bvh->nodesUsed, desc.prim_idx = bvh->primitiveIdx;
+	if (quads_size)
+	{
+		const Quad& q = quads[0]; // scene.h:208, renderer.cpp:483
+		const float4 l[3] = { float4( q.c1, 0 ), float4( q.c2, 0 ), float4( q.c3, 0 ) };
+		memcpy( desc.light_corners, l, 48 );
+		desc.light_A = q.A, desc.light_s = q.s;
+		desc.light_emission[0] = q.material.emission.x, desc.light_emission[1] = q.material.emission.y, desc.light_emission[2] = q.material.emission.z, desc.light_emission[3] = 0;
+		// Scene::GetLightPos (scene.h:343-350), by value instead of the reference's dangling pointer
+		const float3 corner1 = TransformPosition( float3( -q.size, 0, -q.size ), q.T );
+		const float3 corner2 = TransformPosition( float3( q.size, 0, q.size ), q.T );
+		const float3 l0 = ( corner1 + corner2 ) * 0.5f - float3( 0, 0.01f, 0 );
+		desc.whitted_light_pos[0][0] = l0.x, desc.whitted_light_pos[0][1] = l0.y, desc.whitted_light_pos[0][2] = l0.z;
+	}
+	desc.whitted_light_pos[1][0] = lightPos.x, desc.whitted_light_pos[1][1] = lightPos.y, desc.whitted_light_pos[1][2] = lightPos.z;
+	for (int k = 0; k < 2; k++)
+		desc.whitted_light_color[k][0] = lightColors[k].x, desc.whitted_light_color[k][1] = lightColors[k].y, desc.whitted_light_color[k][2] = lightColors[k].z;
+	desc.whitted_intensity = intensity;
+	desc.texture = texture.empty() ? 0 : texture.data(), desc.tex_w = tex_w, desc.tex_h = tex_h;
+	isInitialized = true;
+}
+
+// (p,q) torus knot centre line c(t) = ((R + r cos qt) cos pt, r sin qt, (R + r cos qt) sin pt), swept by a circle of
+// radius `tube` in the (normal, binormal) frame obtained from finite differences.  Evaluated in double, stored as
+// float; closed form, no RNG, so every rank generates the identical mesh.
+void MakeTorusKnot( int nu, int nv, float R, float r, float tube, int p, int q, float3 centre, std::vector<float>& out )
+{
+	const double TWO_PI = 6.283185307179586476925;
+	auto curve = [&]( double t, double* c ) {
+		const double w = R + r * cos( q * t );
+		c[0] = w * cos( p * t ), c[1] = r * sin( q * t ), c[2] = w * sin( p * t ); };
+	std::vector<float> P( (size_t)nu * nv * 3 );
+#pragma omp parallel for schedule( static )
+	for (int i = 0; i < nu; i++)
+	{
+		const double t = TWO_PI * i / nu, h = 1e-4;
+		double c[3], a[3], b[3];
+		curve( t, c ), curve( t - h, a ), curve( t + h, b );
+		double T[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+		double A[3] = { b[0] - 2 * c[0] + a[0], b[1] - 2 * c[1] + a[1], b[2] - 2 * c[2] + a[2] };
+		double tl = sqrt( T[0] * T[0] + T[1] * T[1] + T[2] * T[2] );
+		for (int k = 0; k < 3; k++) T[k] /= tl;
+		double ad = A[0] * T[0] + A[1] * T[1] + A[2] * T[2];
+		double N[3] = { A[0] - ad * T[0], A[1] - ad * T[1], A[2] - ad * T[2] };
+		double nl = sqrt( N[0] * N[0] + N[1] * N[1] + N[2] * N[2] );
+		if (nl < 1e-12) { N[0] = 0, N[1] = 1, N[2] = 0, nl = 1; }
+		for (int k = 0; k < 3; k++) N[k] /= nl;
+		double B[3] = { T[1] * N[2] - T[2] * N[1], T[2] * N[0] - T[0] * N[2], T[0] * N[1] - T[1] * N[0] };
+		for (int j = 0; j < nv; j++)
+		{
+			const double s = TWO_PI * j / nv, cs = cos( s ) * tube, sn = sin( s ) * tube;
+			float* o = &P[( (size_t)i * nv + j ) * 3];
+			o[0] = (float)( c[0] + cs * N[0] + sn * B[0] + centre.x );
+			o[1] = (float)( c[1] + cs * N[1] + sn * B[1] + centre.y );
+			o[2] = (float)( c[2] + cs * N[2] + sn * B[2] + centre.z );
+		}
+	}
+	out.resize( (size_t)nu * nv * 18 );
+#pragma omp parallel for schedule( static )
+	for (int i = 0; i < nu; i++) for (int j = 0; j < nv; j++)
+	{
+		const int i1 = ( i + 1 ) % nu, j1 = ( j + 1 ) % nv;
+		const float* p00 = &P[( (size_t)i * nv + j ) * 3], *p10 = &P[( (size_t)i1 * nv + j ) * 3];
+		const float* p01 = &P[( (size_t)i * nv + j1 ) * 3], *p11 = &P[( (size_t)i1 * nv + j1 ) * 3];
+		float* o = &out[( (size_t)i * nv + j ) * 18];
+		memcpy( o, p00, 12 ), memcpy( o + 3, p10, 12 ), memcpy( o + 6, p11, 12 );
+		memcpy( o + 9, p00, 12 ), memcpy( o + 12, p11, 12 ), memcpy( o + 15, p01, 12 );
+	}
+}
+
+bool WriteObj( const std::string& file, const float* v, size_t ntri )
+{
+	FILE* f = fopen( file.c_str(), "w" );
+	if (!f) return false;
+	fprintf( f, "# rtmi synthetic mesh, %zu triangles\n", ntri );
+	for (size_t i = 0; i < ntri * 3; i++) fprintf( f, "v %.9g %.9g %.9g\n", v[3 * i], v[3 * i + 1], v[3 * i + 2] );
+	for (size_t i = 0; i < ntri; i++) fprintf( f, "f %zu %zu %zu\n", 3 * i + 1, 3 * i + 2, 3 * i + 3 );
+	fclose( f );
+	return true;
+}
+
+} // namespace rtmi
