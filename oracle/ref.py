@@ -142,6 +142,12 @@ class Ref:
         self.L.ref_sample(int(qbvh), _p(seeds0), s_begin, s_count, _p(acc))
         return acc
 
+    def sample_strided(self, seeds0, s_begin, s_count, stride, qbvh=False):
+        acc = np.zeros((self.H, self.W, 4), np.float32)
+        seeds0 = np.ascontiguousarray(seeds0, np.uint32)
+        self.L.ref_sample_strided(int(qbvh), _p(seeds0), s_begin, s_count, stride, _p(acc))
+        return acc
+
     def trace(self, vis, depth=5, qbvh=False, aa=False):
         out = np.zeros((self.H, self.W, 4), np.float32)
         if aa:

@@ -174,12 +174,13 @@ void ref_hit_attribs( int n, const int* objIdx, const float* I, const float* wo,
 
 // Renderer::Sample accumulated exactly like Tick's CPU path (renderer.cpp:559-567), with the
 // per-(pixel,sample) stream of SURVEY A.5.  acc is W*H*4 floats, caller-zeroed for s_begin==0.
-void ref_sample( int useQBVH, const uint* seeds0, int s_begin, int s_count, float* acc )
+void ref_sample_strided( int useQBVH, const uint* seeds0, int s_begin, int s_count, int stride, float* acc )
 {
 	R->scene.SetQBVH( useQBVH != 0 );
 	R->visualizationMode = Renderer::PathTracing;
-	for (int s = s_begin; s < s_begin + s_count; s++)
+	for (int k = 0; k < s_count; k++)
 	{
+		const int s = s_begin + k * stride;
 #pragma omp parallel for schedule( dynamic )
 		for (int y = 0; y < SCRHEIGHT; y++) for (int x = 0; x < SCRWIDTH; x++)
 		{
@@ -192,6 +193,7 @@ void ref_sample( int useQBVH, const uint* seeds0, int s_begin, int s_count, floa
 	}
 	R->scene.SetQBVH( true );
 }
+void ref_sample( int useQBVH, const uint* seeds0, int s_begin, int s_count, float* acc ) { ref_sample_strided( useQBVH, seeds0, s_begin, s_count, 1, acc ); }
 // Renderer::Trace for the non-path-tracing modes (renderer.cpp:578-592); vis = enum renderer.h:9
 void ref_trace( int useQBVH, int vis, int depth, float* out )
 {
