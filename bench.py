@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mrays/s, path-traced ~1M-triangle scene at 1920x1080 (BASELINE.json configs[2]).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one Renderer::Tick-equivalent pass of the hot path over one batch: every rank
+path-traces --spp-per-step samples for every pixel (ray generation, extend, shade, connect, ... until every path
+has terminated) and adds them into its float4 accumulator in HBM.  Samples are split by index over the ranks
+(rank r renders sample indices r, r+N, r+2N, ...), so per-GPU work is fixed as N grows (weak scaling:
+N GPUs deliver N x K x spp-per-step samples per pixel).  At the end of the timed region the accumulators are
+summed onto rank 0 with ONE RCCL reduce (torch.distributed, backend nccl) and rank 0 converts to RGB8 on device.
+Scene, BVH, camera, seed table and all queues are resident in HBM before the timed region starts.
+
+value = (closest-hit + any-hit rays traversed by all ranks, from device counters) / (max over ranks of the time of
+the K steps + reduce + finalize), in Mrays/s.  The reference's own "Mrays/s" (primary samples/s, renderer.cpp:639)
+is reported beside it as mpaths_per_s.
+
+roofline: the dominant kernel is k_extend (closest-hit BVH traversal).  achieved = algorithmic bytes of all
+k_extend launches of the timed region / their summed duration measured with hipEvents recorded on the stream the
+kernels run on (inside librtmi, rtmi_set_profiling), i.e. bytes per launch / mean launch duration.  Algorithmic bytes
+per extend ray = 64 B x node-pair records fetched + 48 B x leaf primitive records tested + 44 B of ray state
+(SURVEY 8d); the per-ray record counts come from a counting pass of the same kernels over the first step's samples.
+
+cpu_baseline: the CPU restatement (oracle/, kind "port"; validated bit-exact against the compiled reference) timed
+on this box's host cores over a bounded row subset of one sample of the same workload.  N=1, rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--tris", type=int, default=1000000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--builder", choices=["binned", "reference"], default="binned")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
+                    help="HBM bytes per k_extend launch from a separate rocprofv3 --pmc run (profiles/), else null")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the trace loop has no CPU path (see oracle/ for the checker)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = a.width, a.height
+    t0 = time.time()
+    scene = api.mesh_scene(a.tris, api.BINNED_SAH if a.builder == "binned" else api.REFERENCE_SAH)
+    info = scene.info()
+    build_s = time.time() - t0
+    dev = api.Device(W, H, local_rank)
+    dev.upload(scene.desc)
+    dev.set_camera(api.default_camera(W, H))
+    seeds = api.seed_table(W * H)
+    dev.set_seeds(seeds)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    dev.set_stream(stream.cuda_stream)
+    dev.set_accumulator(acc.data_ptr())
+    spp = a.spp_per_step
+
+    def step(i):
+        # global sample index of this rank's k-th sample of step i: (i*spp + k)*world + rank
+        dev.render(api.PATHTRACING, (i * spp) * world + rank, spp, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # counting pass (not timed): node-pair / primitive records per ray on this workload
+    dev.set_profiling(False, True)
+    dev.reset_stats()
+    step(0)
+    dev.sync()
+    cs = dev.stats()
+    pairs_per_ray = cs["extend_pairs"] / max(1, cs["extend_rays"])
+    prims_per_ray = cs["extend_prims"] / max(1, cs["extend_rays"])
+    spairs_per_ray = cs["shadow_pairs"] / max(1, cs["shadow_rays"])
+    sprims_per_ray = cs["shadow_prims"] / max(1, cs["shadow_rays"])
+    dev.set_profiling(False, False)
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    acc.zero_()
+    dev.set_profiling(True, False)
+    dev.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    if world > 1:
+        dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 16*W*H bytes, once
+    pixels = dev.finalize(a.steps * spp * world) if rank == 0 else None
+    barrier()
+    dt = time.perf_counter() - t0
+    st = dev.stats()
+    dev.set_profiling(False, False)
+
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([st["extend_rays"] + st["shadow_rays"], st["extend_rays"], st["shadow_rays"], st["primary_samples"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    dt = float(tt.item())
+    total_rays, ext_rays, sh_rays, paths = [float(x) for x in rays.tolist()]
+
+    if rank == 0:
+        bytes_per_extend_ray = 64.0 * pairs_per_ray + 48.0 * prims_per_ray + 44.0
+        ext_bytes = st["extend_rays"] * bytes_per_extend_ray
+        ext_s = st["ms_extend"] * 1e-3
+        n_launch = max(1, st["n_extend_launches"])
+        achieved = ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
+        peak = 8000.0
+        out = {
+            "metric": "Mrays/s (whole node), path-traced OBJ scene 1080p", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: path-traced torus-knot scene in the reference room, %d triangles, %dx%d, %d spp per step per GPU, "
+                                   "samples split by index over ranks, one RCCL reduce + RGB8 finalize at the end" % (info["triangles"], W, H, spp),
+                       "triangles": info["triangles"], "bvh_nodes": info["nodes_used"], "bvh_depth": info["max_depth"], "builder": a.builder,
+                       "width": W, "height": H, "spp_per_step": spp, "total_spp": a.steps * spp * world, "parallelism": "sample-split x%d" % world},
+            "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays, "rays_per_path": total_rays / max(1.0, paths),
+            "scene_build_s": build_s,
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "traffic": a.traffic_bytes_per_launch, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
+                         "launches": st["n_extend_launches"], "bytes_per_ray": bytes_per_extend_ray, "node_pairs_per_ray": pairs_per_ray,
+                         "leaf_prims_per_ray": prims_per_ray, "shadow_node_pairs_per_ray": spairs_per_ray, "shadow_leaf_prims_per_ray": sprims_per_ray},
+            "kernel_ms": {"extend": st["ms_extend"], "shade": st["ms_shade"], "connect": st["ms_connect"], "other": st["ms_other"]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, seeds, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, W, H, seeds, budget_s):
+    """The oracle (CPU port of Renderer::Sample, OpenMP rows like renderer.cpp:561) on the host cores of this box,
+    one sample per pixel over every `row_step`-th row, sized to about `budget_s` seconds."""
+    from raytracer_amd import api
+    from oracle.oracle import Oracle
+    share = os.environ.get("OMP_NUM_THREADS")
+    orc = Oracle(scene.desc)
+    if not share:
+        orc.set_threads(min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
+    cores = orc.max_threads()
+    cam = api.default_camera(W, H)
+    # calibrate on every 64th row
+    c = np.zeros(7, np.uint64)
+    t0 = time.perf_counter()
+    orc.sample_rows(W, H, cam, seeds, 0, 1, 1, 0, 64, None, c)
+    cal = time.perf_counter() - t0
+    rows_cal = len(range(0, H, 64))
+    per_row = cal / rows_cal
+    row_step = max(1, int(np.ceil(H * per_row / budget_s)))
+    c = np.zeros(7, np.uint64)
+    t0 = time.perf_counter()
+    orc.sample_rows(W, H, cam, seeds, 0, 1, 1, 0, row_step, None, c)
+    dt = time.perf_counter() - t0
+    rows = len(range(0, H, row_step))
+    rays = float(c[0] + c[1])
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": int(cores), "kind": "port",
+            "sample": "1 spp over %d of %d rows (every %d-th) of the same %dx%d workload, %.1f s" % (rows, H, row_step, W, H, dt),
+            "mpaths_per_s": rows * W / dt / 1e6, "node_tests_per_extend_ray": float(c[2]) / max(1.0, float(c[0])),
+            "prim_tests_per_extend_ray": float(c[3]) / max(1.0, float(c[0]))}
+
+
+if __name__ == "__main__":
+    main()

@@ -598,7 +598,8 @@ void orc_hit_attribs( void* h, int n, const int* obj, const float* I, const floa
 // accumulator[p] += Sample(primary ray p) for samples s_begin, s_begin+stride, ... (renderer.cpp:559-567); rows in
 // parallel like the reference's `#pragma omp parallel for schedule(dynamic)` (renderer.cpp:561).
 // counters (may be null): extend rays, shadow rays, closest-hit nodes, closest-hit prims, rng draws, any-hit nodes, any-hit prims
-void orc_sample( void* h, int W, int H, const float* cam, const uint32_t* seeds0, int s_begin, int s_count, int stride, float* acc, unsigned long long* counters )
+void orc_sample_rows( void* h, int W, int H, const float* cam, const uint32_t* seeds0, int s_begin, int s_count, int stride, int row_begin, int row_step,
+	float* acc, unsigned long long* counters )
 {
 	const Oracle* o = (Oracle*)h;
 	Counters total;
@@ -609,7 +610,7 @@ void orc_sample( void* h, int W, int H, const float* cam, const uint32_t* seeds0
 		{
 			Counters local;
 #pragma omp for schedule( dynamic )
-			for (int y = 0; y < H; y++) for (int x = 0; x < W; x++)
+			for (int y = row_begin; y < H; y += row_step) for (int x = 0; x < W; x++)
 			{
 				const size_t p = (size_t)x + (size_t)y * W;
 				uint seed = sample_seed( seeds0[p], s );
@@ -626,6 +627,10 @@ void orc_sample( void* h, int W, int H, const float* cam, const uint32_t* seeds0
 	if (counters)
 		counters[0] += total.extend, counters[1] += total.shadow, counters[2] += total.nodes, counters[3] += total.prims, counters[4] += total.draws,
 		counters[5] += total.snodes, counters[6] += total.sprims;
+}
+void orc_sample( void* h, int W, int H, const float* cam, const uint32_t* seeds0, int s_begin, int s_count, int stride, float* acc, unsigned long long* counters )
+{
+	orc_sample_rows( h, W, H, cam, seeds0, s_begin, s_count, stride, 0, 1, acc, counters );
 }
 // accumulator[p] = Trace(primary ray p, 0) (renderer.cpp:578-618)
 void orc_trace( void* h, int W, int H, const float* cam, int mode, int maxDepth, int aa, float* out )
