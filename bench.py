@@ -178,23 +178,24 @@ def cpu_baseline(scene, W, H, seeds, budget_s):
         orc.set_threads(min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
     cores = orc.max_threads()
     cam = api.default_camera(W, H)
-    # calibrate on every 64th row
+    # calibrate on every 64th row, then size the sample to about budget_s: a row subset of one sample when a whole
+    # frame is too slow, else several whole samples per pixel
     c = np.zeros(7, np.uint64)
     t0 = time.perf_counter()
     orc.sample_rows(W, H, cam, seeds, 0, 1, 1, 0, 64, None, c)
-    cal = time.perf_counter() - t0
-    rows_cal = len(range(0, H, 64))
-    per_row = cal / rows_cal
-    row_step = max(1, int(np.ceil(H * per_row / budget_s)))
+    per_row = (time.perf_counter() - t0) / len(range(0, H, 64))
+    frame_s = H * per_row
+    row_step = max(1, int(np.ceil(frame_s / budget_s)))
+    n_spp = max(1, int(budget_s / frame_s)) if row_step == 1 else 1
     c = np.zeros(7, np.uint64)
     t0 = time.perf_counter()
-    orc.sample_rows(W, H, cam, seeds, 0, 1, 1, 0, row_step, None, c)
+    orc.sample_rows(W, H, cam, seeds, 0, n_spp, 1, 0, row_step, None, c)
     dt = time.perf_counter() - t0
     rows = len(range(0, H, row_step))
     rays = float(c[0] + c[1])
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": int(cores), "kind": "port",
-            "sample": "1 spp over %d of %d rows (every %d-th) of the same %dx%d workload, %.1f s" % (rows, H, row_step, W, H, dt),
-            "mpaths_per_s": rows * W / dt / 1e6, "node_tests_per_extend_ray": float(c[2]) / max(1.0, float(c[0])),
+            "sample": "%d spp over %d of %d rows (every %d-th) of the same %dx%d workload, %.1f s" % (n_spp, rows, H, row_step, W, H, dt),
+            "mpaths_per_s": n_spp * rows * W / dt / 1e6, "node_tests_per_extend_ray": float(c[2]) / max(1.0, float(c[0])),
             "prim_tests_per_extend_ray": float(c[3]) / max(1.0, float(c[0]))}
 
 
