@@ -270,6 +270,38 @@ __device__ __forceinline__ bool traverse( const DScene& s, f3 O, f3 D, f3 rD, Ra
 	return false;
 }
 
+// ---- the same traversal cut into steps, for the persistent kernels that refill idle lanes with new rays ----------
+template <bool EXACT>
+__device__ __forceinline__ uint32_t bvh_enter( const DScene& s, f3 O, f3 rD, float t )
+{
+	float tmin, tmax;
+	slab<EXACT>( s.root_min[0], s.root_min[1], s.root_min[2], s.root_max[0], s.root_max[1], s.root_max[2], O, rD, tmin, tmax );
+	return ( tmax >= tmin && tmin < t && tmax > 0 ) ? s.root_ref : RT_DONE;
+}
+// one interior node: tests both children of pair `cur`, descends into the nearer hit child, pushes the other
+template <bool ANY, bool EXACT>
+__device__ __forceinline__ uint32_t interior_step( const DScene& s, uint32_t cur, f3 O, f3 rD, float t, uint32_t* stack, const int stride, int& sp )
+{
+	const float4 q0 = s.pairs[4 * cur], q1 = s.pairs[4 * cur + 1], q2 = s.pairs[4 * cur + 2], q3 = s.pairs[4 * cur + 3];
+	float tminL, tmaxL, tminR, tmaxR;
+	slab<EXACT>( q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, O, rD, tminL, tmaxL );
+	slab<EXACT>( q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, O, rD, tminR, tmaxR );
+	const bool hitL = tmaxL >= tminL && ( ANY ? tminL < t : tminL <= t ) && tmaxL > 0;
+	const bool hitR = tmaxR >= tminR && ( ANY ? tminR < t : tminR <= t ) && tmaxR > 0;
+	const uint32_t refL = __float_as_uint( q1.z ), refR = __float_as_uint( q3.z );
+	if (hitL && hitR)
+	{
+		const bool swap = tminR < tminL;
+		stack[sp * stride] = swap ? refL : refR;
+		sp++;
+		return swap ? refR : refL;
+	}
+	if (hitL) return refL;
+	if (hitR) return refR;
+	if (sp > 0) return stack[--sp * stride];
+	return RT_DONE;
+}
+
 // Scene::FindNearest (scene.h:359-368): quads[0], cubes[0], planes, BVH.  h.t carries the ray's tmax in.
 template <bool COUNT>
 __device__ __forceinline__ void find_nearest( const DScene& s, f3 O, f3 D, RayHit& h, uint32_t* stack, int stride, TravCount& cnt )

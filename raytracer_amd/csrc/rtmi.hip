@@ -47,6 +47,10 @@ struct DevCounters // zeroed per render batch
 {
 	uint32_t next[2];      // ping-pong bounce queue lengths
 	uint32_t shadow;       // shadow queue length of the current bounce
+	uint32_t pool_extend;  // next unclaimed ray of the running k_trace<closest> launch (persistent waves pull from it)
+	uint32_t pool_connect; // same for k_trace<any>
+	uint32_t tq_extend;    // rays of the current bounce that have to walk the BVH (k_setup -> k_trace)
+	uint32_t tq_connect;
 	uint32_t pad;
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims;
 };
@@ -122,6 +126,183 @@ __global__ __launch_bounds__( BLOCK ) void k_extend( DScene s, PathState st, con
 		wave_add64( tc.prims, &ctr->extend_prims );
 	}
 	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->extend_rays, (unsigned long long)n );
+}
+
+// ---- two-step traversal: coherent setup, then persistent BVH walk with lane refill ---------------------------------
+// rocprof of the one-ray-per-thread kernels showed 5 % of VALU lane-cycles active on bounce rays: most rays never
+// enter the BVH (they hit a wall, the light or nothing) and sit idle in a wave until its longest ray is done.
+//   k_setup  one ray per lane, every lane busy: ray generation / queue read, the analytic primitives of
+//            Scene::FindNearest / IsOccluded (quad, cube, planes), reciprocal direction, root box test.  Rays that do
+//            not reach the BVH are finished here; the others are appended (ballot + prefix, one atomic per wave) to the
+//            bounce's traversal queue.
+//   k_trace  a fixed number of resident waves pull from that queue; whenever `refill` lanes of a wave are idle they
+//            get new rays (one atomic per refill), so lanes stay busy although traversal lengths differ widely.
+// Per-ray arithmetic is the same as in k_extend / k_connect, so results are identical.
+template <bool ANY, bool PRIMARY>
+__global__ __launch_bounds__( BLOCK ) void k_setup( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
+	uint32_t n_primary, CamProp cam, int W, int H, float invW, float invH, DevCounters* ctr, uint32_t* __restrict__ tq, uint32_t* tq_count )
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t n = PRIMARY ? n_primary : *count_ptr;
+	bool walk = false;
+	uint32_t entry = 0;
+	if (i < n)
+	{
+		f3 O, D;
+		uint32_t slot;
+		RayHit h; h.obj = -1, h.pos = -1;
+		if (ANY)
+		{
+			const float4 ot = sq.o_t[i], ds = sq.d_s[i];
+			O = mk3( ot ), D = mk3( ds ), h.t = ot.w, slot = __float_as_uint( ds.w ), entry = i;
+		}
+		else if (PRIMARY)
+		{
+			slot = i, entry = i;
+			const uint32_t p = i % (uint32_t)( W * H );
+			primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
+			h.t = 1e34f;
+		}
+		else
+		{
+			slot = queue[i], entry = slot;
+			O = mk3( st.o_t[slot] ), D = mk3( st.d_h[slot] ), h.t = 1e34f;
+		}
+		bool occluded = false;
+		if (ANY)
+		{
+			if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
+			if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
+			for (int k = 0; k < s.n_planes && h.obj == -1; k++) isect_plane( s, k, O, D, h );
+			occluded = h.obj != -1;
+		}
+		else isect_analytic( s, O, D, h );
+		if (!occluded && s.n_bvh_prims > 0)
+		{
+			const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+			const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+			walk = ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
+		}
+		if (ANY)
+		{
+			if (!occluded && !walk)
+			{
+				const float4 c = sq.c[i];
+				float4 e = st.E_f[slot];
+				e.x += c.x, e.y += c.y, e.z += c.z;
+				st.E_f[slot] = e;
+			}
+		}
+		else if (PRIMARY)
+		{
+			st.o_t[slot] = make_float4( O.x, O.y, O.z, h.t );
+			st.d_h[slot] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+		}
+		else
+		{
+			st.o_t[slot].w = h.t;
+			st.d_h[slot].w = __int_as_float( h.obj );
+		}
+	}
+	const uint32_t qi = wave_append( walk, tq_count );
+	if (walk) tq[qi] = entry;
+	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( ANY ? &ctr->shadow_rays : &ctr->extend_rays, (unsigned long long)n );
+}
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ tq, const uint32_t* __restrict__ count_ptr,
+	DevCounters* ctr, uint32_t* pool, int refill )
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t* stack = lds_stack + threadIdx.x;
+	const uint32_t n = *count_ptr;
+	const int lane = threadIdx.x & 63;
+	bool has = false, exhausted = false, inexact = false, occluded = false;
+	uint32_t cur = RT_DONE, entry = 0, slot = 0;
+	int sp = 0;
+	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), rD = mk3( 0, 0, 1 );
+	RayHit h; h.t = 0, h.obj = -1, h.pos = -1;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	for (;;)
+	{
+		const unsigned long long idle = __ballot( !has );
+		const int nIdle = __popcll( idle );
+		if (!exhausted && nIdle >= refill)
+		{
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd( pool, (uint32_t)nIdle );
+			base = __shfl( base, 0, 64 );
+			if (base + (uint32_t)nIdle >= n) exhausted = true;
+			const uint32_t my = base + __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0 ) );
+			if (!has && my < n)
+			{
+				entry = tq[my], has = true, sp = 0, occluded = false, h.pos = -1;
+				if (ANY)
+				{
+					const float4 ot = sq.o_t[entry], ds = sq.d_s[entry];
+					O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
+				}
+				else
+				{
+					slot = entry;
+					const float4 ot = st.o_t[slot], dh = st.d_h[slot];
+					O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far (k_setup)
+				}
+				rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+				inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+				cur = s.root_ref; // the root box test passed in k_setup
+			}
+		}
+		if (__ballot( has ) == 0)
+		{
+			if (exhausted) break;
+			continue;
+		}
+		if (__ballot( has && inexact ) != 0)
+		{
+			while (!( cur & RT_LEAF )) { if (COUNT) tc.pairs++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+		}
+		else
+		{
+			while (!( cur & RT_LEAF )) { if (COUNT) tc.pairs++; cur = interior_step<ANY, false>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+		}
+		if (cur != RT_DONE)
+		{
+			const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
+			bool hit = false;
+			for (int i = 0; i < count && !( ANY && hit ); i++)
+			{
+				if (COUNT) tc.prims++;
+				hit = isect_prim<ANY>( s, first + i, O, D, h );
+			}
+			if (ANY && hit) occluded = true, cur = RT_DONE;
+			else cur = sp > 0 ? stack[--sp * BLOCK] : RT_DONE;
+		}
+		if (has && cur == RT_DONE)
+		{
+			if (ANY)
+			{
+				if (!occluded)
+				{
+					const float4 c = sq.c[entry];
+					float4 e = st.E_f[slot];
+					e.x += c.x, e.y += c.y, e.z += c.z;
+					st.E_f[slot] = e;
+				}
+			}
+			else if (h.pos >= 0) // a BVH primitive beat the analytic hit
+			{
+				st.o_t[slot].w = h.t;
+				st.d_h[slot].w = __int_as_float( h.obj );
+			}
+			has = false, inexact = false;
+		}
+	}
+	if (COUNT)
+	{
+		wave_add64( tc.pairs, ANY ? &ctr->shadow_pairs : &ctr->extend_pairs );
+		wave_add64( tc.prims, ANY ? &ctr->shadow_prims : &ctr->extend_prims );
+	}
 }
 
 // ---- shade: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361) -----------------------------
@@ -304,7 +485,7 @@ __global__ __launch_bounds__( BLOCK ) void k_connect( DScene s, PathState st, Sh
 }
 
 // the shadow count of a bounce is consumed by k_connect of the same bounce; reset it for the next one
-__global__ void k_reset_shadow( DevCounters* ctr, int which_next ) { ctr->shadow = 0; ctr->next[which_next] = 0; }
+__global__ void k_reset_shadow( DevCounters* ctr, int which_next ) { ctr->shadow = 0; ctr->next[which_next] = 0; ctr->pool_extend = 0; ctr->pool_connect = 0; ctr->tq_extend = 0; ctr->tq_connect = 0; }
 
 // ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
 __global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E_f, int WH, int S )
@@ -576,6 +757,10 @@ struct rtmi_ctx
 	DScene ds = {};
 	std::vector<void*> scene_allocs;
 	int stack_depth = 8;
+	bool persistent = true; // k_trace (persistent waves + lane refill) instead of one ray per thread
+	int refill = 16;        // refill a wave when at least this many lanes are idle
+	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
+	int n_cus = 256;
 	CamProp cam = {};
 	uint32_t* seeds = 0;
 	float4* accum_own = 0;
@@ -586,6 +771,7 @@ struct rtmi_ctx
 	PathState st = {};
 	ShadowQueue sq = {};
 	uint32_t* queue[2] = { 0, 0 };
+	uint32_t* tq[2] = { 0, 0 }; // traversal queues: [0] closest hit, [1] any hit
 	DevCounters* ctr = 0;
 	uint32_t* host_counts = 0; // pinned ring of read-back queue lengths
 	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
@@ -663,9 +849,9 @@ static void free_scene( rtmi_ctx* c )
 }
 static void free_batch( rtmi_ctx* c )
 {
-	void* ps[] = { c->st.o_t, c->st.d_h, c->st.T_s, c->st.E_f, c->sq.o_t, c->sq.d_s, c->sq.c, c->queue[0], c->queue[1] };
+	void* ps[] = { c->st.o_t, c->st.d_h, c->st.T_s, c->st.E_f, c->sq.o_t, c->sq.d_s, c->sq.c, c->queue[0], c->queue[1], c->tq[0], c->tq[1] };
 	for (void* p : ps) if (p) (void)hipFree( p );
-	c->st = PathState{}, c->sq = ShadowQueue{}, c->queue[0] = c->queue[1] = 0, c->batch = 0;
+	c->st = PathState{}, c->sq = ShadowQueue{}, c->queue[0] = c->queue[1] = 0, c->tq[0] = c->tq[1] = 0, c->batch = 0;
 }
 static int ensure_batch( rtmi_ctx* c, int S )
 {
@@ -675,7 +861,7 @@ static int ensure_batch( rtmi_ctx* c, int S )
 	int r;
 	if (( r = dev_alloc( c, &c->st.o_t, n ) ) || ( r = dev_alloc( c, &c->st.d_h, n ) ) || ( r = dev_alloc( c, &c->st.T_s, n ) ) || ( r = dev_alloc( c, &c->st.E_f, n ) ) ||
 		( r = dev_alloc( c, &c->sq.o_t, n ) ) || ( r = dev_alloc( c, &c->sq.d_s, n ) ) || ( r = dev_alloc( c, &c->sq.c, n ) ) ||
-		( r = dev_alloc( c, &c->queue[0], n ) ) || ( r = dev_alloc( c, &c->queue[1], n ) )) { free_batch( c ); return r; }
+		( r = dev_alloc( c, &c->queue[0], n ) ) || ( r = dev_alloc( c, &c->queue[1], n ) ) || ( r = dev_alloc( c, &c->tq[0], n ) ) || ( r = dev_alloc( c, &c->tq[1], n ) )) { free_batch( c ); return r; }
 	c->batch = S;
 	return RTMI_OK;
 }
@@ -698,6 +884,14 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	if (hipSetDevice( device_id ) != hipSuccess) return bail( RTMI_ERR_HIP );
 	if (hipStreamCreateWithFlags( &c->own_stream, hipStreamNonBlocking ) != hipSuccess) return bail( RTMI_ERR_HIP );
 	c->stream = c->own_stream;
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties( &prop, device_id ) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+		const char* e = getenv( "RTMI_PERSISTENT" );
+		if (e) c->persistent = atoi( e ) != 0;
+		e = getenv( "RTMI_REFILL" );
+		if (e && atoi( e ) >= 1 && atoi( e ) <= 64) c->refill = atoi( e );
+	}
 	const size_t n = (size_t)width * height;
 	if (dev_alloc( c, &c->seeds, n ) || dev_alloc( c, &c->accum_own, n ) || dev_alloc( c, &c->pixels, n ) || dev_alloc( c, &c->pixels2, n ) ||
 		dev_alloc( c, &c->gamma_lut, 256 ) || dev_alloc( c, &c->ctr, 1 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
@@ -910,6 +1104,12 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	free_scene( c );
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
+	{
+		// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 8 (32 waves per CU)
+		const size_t per_block = (size_t)c->stack_depth * BLOCK * sizeof( uint32_t );
+		const int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) );
+		c->max_blocks = c->n_cus * per_cu;
+	}
 	return RTMI_OK;
 }
 
@@ -952,13 +1152,43 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 	const float invW = 1.0f / c->W, invH = 1.0f / c->H; // camera.h:31-32
 	const size_t lds = stack_bytes( c );
 	hipStream_t s = c->stream;
-	HIPCHK( hipMemsetAsync( c->ctr, 0, 16, s ) ); // next[2], shadow, pad
+	HIPCHK( hipMemsetAsync( c->ctr, 0, 32, s ) ); // next[2], shadow, pools, pad
 	const bool cn = c->count_nodes;
-	{
+	const int refill = c->refill;
+	// persistent launches: as many waves as stay resident (LDS stack bound), never more than the rays need
+	auto pgrid = [&]( uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); };
+	auto extend = [&]( bool primary, uint32_t rays, const uint32_t* queue, const uint32_t* count_ptr ) {
 		ScopedTimer t( c, 0 );
-		if (cn) hipLaunchKernelGGL( ( k_extend<true, true> ), dim3( nblocks( N ) ), dim3( BLOCK ), lds, s, c->ds, c->st, nullptr, nullptr, N, c->cam, c->W, c->H, invW, invH, c->ctr );
-		else hipLaunchKernelGGL( ( k_extend<true, false> ), dim3( nblocks( N ) ), dim3( BLOCK ), lds, s, c->ds, c->st, nullptr, nullptr, N, c->cam, c->W, c->H, invW, invH, c->ctr );
-	}
+		if (c->persistent)
+		{
+			if (primary) hipLaunchKernelGGL( ( k_setup<false, true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, queue, count_ptr, rays, c->cam, c->W, c->H, invW, invH, c->ctr, c->tq[0], &c->ctr->tq_extend );
+			else hipLaunchKernelGGL( ( k_setup<false, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, queue, count_ptr, 0u, c->cam, c->W, c->H, invW, invH, c->ctr, c->tq[0], &c->ctr->tq_extend );
+			if (cn) hipLaunchKernelGGL( ( k_trace<false, true> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[0], &c->ctr->tq_extend, c->ctr, &c->ctr->pool_extend, refill );
+			else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[0], &c->ctr->tq_extend, c->ctr, &c->ctr->pool_extend, refill );
+		}
+		else if (primary)
+		{
+			if (cn) hipLaunchKernelGGL( ( k_extend<true, true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, rays, c->cam, c->W, c->H, invW, invH, c->ctr );
+			else hipLaunchKernelGGL( ( k_extend<true, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, rays, c->cam, c->W, c->H, invW, invH, c->ctr );
+		}
+		else
+		{
+			if (cn) hipLaunchKernelGGL( ( k_extend<false, true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
+			else hipLaunchKernelGGL( ( k_extend<false, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
+		}
+	};
+	auto connect = [&]( uint32_t rays ) {
+		ScopedTimer t( c, 2 );
+		if (c->persistent)
+		{
+			hipLaunchKernelGGL( ( k_setup<true, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, nullptr, &c->ctr->shadow, 0u, c->cam, c->W, c->H, invW, invH, c->ctr, c->tq[1], &c->ctr->tq_connect );
+			if (cn) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[1], &c->ctr->tq_connect, c->ctr, &c->ctr->pool_connect, refill );
+			else hipLaunchKernelGGL( ( k_trace<true, false> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[1], &c->ctr->tq_connect, c->ctr, &c->ctr->pool_connect, refill );
+		}
+		else if (cn) hipLaunchKernelGGL( ( k_connect<true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
+		else hipLaunchKernelGGL( ( k_connect<false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
+	};
+	extend( true, N, nullptr, nullptr );
 	{
 		ScopedTimer t( c, 1 );
 		hipLaunchKernelGGL( ( k_shade<true> ), dim3( nblocks( N ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, nullptr, c->queue[0], nullptr, N, c->seeds, WH, sample_begin, stride,
@@ -969,12 +1199,7 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 	int cur = 0;        // queue[cur] / next[cur] feed the next extend
 	for (int bounce = 0;; bounce++)
 	{
-		// connect for this bounce's shadow rays (at most `upper` of them)
-		{
-			ScopedTimer t( c, 2 );
-			if (cn) hipLaunchKernelGGL( ( k_connect<true> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
-			else hipLaunchKernelGGL( ( k_connect<false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
-		}
+		connect( upper ); // this bounce's shadow rays (at most `upper` of them)
 		c->stats.bounce_launches++;
 		// read back the length of the queue that feeds bounce+1, two iterations late
 		const int slot = bounce & 3;
@@ -988,11 +1213,7 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 		}
 		if (upper == 0) break;
 		hipLaunchKernelGGL( k_reset_shadow, dim3( 1 ), dim3( 1 ), 0, s, c->ctr, cur ^ 1 );
-		{
-			ScopedTimer t( c, 0 );
-			if (cn) hipLaunchKernelGGL( ( k_extend<false, true> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->queue[cur], &c->ctr->next[cur], 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
-			else hipLaunchKernelGGL( ( k_extend<false, false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->queue[cur], &c->ctr->next[cur], 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
-		}
+		extend( false, upper, c->queue[cur], &c->ctr->next[cur] );
 		{
 			ScopedTimer t( c, 1 );
 			hipLaunchKernelGGL( ( k_shade<false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, c->queue[cur], c->queue[cur ^ 1], &c->ctr->next[cur], 0u, c->seeds, WH,
@@ -1030,7 +1251,7 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 	{
 		if (sample_count <= 0 || sample_stride <= 0 || sample_begin < 0) return fail( c, RTMI_ERR_INVALID, "bad sample range" );
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
-		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 23 ) / WH ) );
+		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
 		const char* env = getenv( "RTMI_BATCH" );
 		if (env && atoi( env ) > 0) S = std::min( sample_count, atoi( env ) );
 		int r = ensure_batch( c, S );
