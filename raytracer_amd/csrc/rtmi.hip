@@ -1,12 +1,15 @@
 // rtmi.hip -- librtmi.so: the C ABI of include/rtmi.h over hand-written gfx950 kernels.
 //
 // Wavefront path tracer (north star): per render batch of S samples x W*H pixels
-//   k_extend<PRIMARY>   ray generation fused with closest-hit traversal for bounce 0     (camera.h:28-35, scene.h:359-368)
-//   k_shade             material evaluation, NEE shadow-ray emission, Russian roulette, next ray; survivors and
-//                       shadow rays are appended to HBM queues with one atomic per wave (ballot + mbcnt prefix)
-//                                                                                        (renderer.cpp:246-365)
-//   k_connect           any-hit traversal of the shadow queue, E[slot] += contribution    (scene.h:369-379, renderer.cpp:339-344)
-//   k_extend            closest-hit traversal of the bounce queue
+//   k_primary           ray generation: camera ray, per-(pixel, sample) rng state, analytic part of FindNearest,
+//                       root box test                                                      (camera.h:28-35, scene.h:359-368)
+//   per bounce:
+//   k_trace<closest>    persistent waves walk the BVH for the rays that entered its root box (bvh.h:507-530)
+//   k_shade             material evaluation, NEE, Russian roulette (renderer.cpp:246-365); CREATES the next ray and the
+//                       shadow ray and runs their analytic intersections + root box tests; survivors are written in
+//                       queue order to the other state set, BVH walkers are appended to the walk / shadow queues with
+//                       one atomic per 1024-thread block (ballot + mbcnt prefix per wave, LDS scan across waves)
+//   k_trace<any>        any-hit walk of the shadow queue, E[slot] += contribution          (scene.h:369-379, renderer.cpp:339-344)
 //   k_accumulate        accumulator[p] += E[sample][p] in sample order                    (renderer.cpp:566-567)
 //   k_finalize, k_gamma, k_chroma, k_vignette                                             (precomp.h:431-465, postprocessing.h)
 //   k_whitted           Renderer::Trace for the non-path-tracing modes, one thread per pixel with an explicit
@@ -25,47 +28,69 @@
 #include <cmath>
 #include <cstdlib>
 
-#define BLOCK 256
+#define BLOCK 256   // traversal and per-pixel kernels
+#define SBLOCK 1024 // shading / ray-generation kernels: one queue-append atomic per 1024 paths (see block_append)
 
-// ---- per-path state, SoA over slots (slot = sample_in_batch * W*H + pixel) ------------------------------------
+// ---- per-path state in QUEUE ORDER (entry i of the current bounce), ping-ponged between bounces: k_shade reads entry i
+// with fully coalesced loads and writes the survivors to consecutive entries of the other set ---------------------------
 struct PathState
 {
-	float4* o_t;  // ray origin, hit distance
-	float4* d_h;  // ray direction, hit object index (int bits)
-	float4* T_s;  // throughput, rng state (uint bits)
-	float4* E_f;  // radiance estimate of this sample so far, flags (bit0 lastSpecular, bit1 inside)
+	float4* o_t;    // ray origin, hit distance
+	float4* d_h;    // ray direction, hit object index (int bits)
+	float4* T_s;    // throughput, rng state (uint bits)
+	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel) | flags << 30
 };
-struct ShadowQueue
+struct ShadowQueue // only the shadow rays that have to walk the BVH
 {
 	float4* o_t;   // origin, tmax
-	float4* d_s;   // direction, slot (int bits)
+	float4* d_s;   // direction, slot (uint bits)
 	float4* c;     // contribution if unoccluded
 };
 struct CamProp { float4 pos, tl, tr, bl; };
 
-struct DevCounters // zeroed per render batch
+struct DevCounters // the first 32 bytes are zeroed per render batch
 {
-	uint32_t next[2];      // ping-pong bounce queue lengths
-	uint32_t shadow;       // shadow queue length of the current bounce
-	uint32_t pool_extend;  // next unclaimed ray of the running k_trace<closest> launch (persistent waves pull from it)
+	uint32_t n_state[2];   // ping-pong path queue lengths
+	uint32_t n_walk[2];    // rays of that queue that enter the BVH root box (indices in wq[])
+	uint32_t n_shadow;     // shadow queue length of the current bounce
+	uint32_t pool_extend;  // next unclaimed entry of the running k_trace<closest> launch (persistent waves pull chunks from it)
 	uint32_t pool_connect; // same for k_trace<any>
-	uint32_t tq_extend;    // rays of the current bounce that have to walk the BVH (k_setup -> k_trace)
-	uint32_t tq_connect;
 	uint32_t pad;
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims;
 };
 
-// ---- wave-level queue append: one atomic per wave -------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_append( bool push, uint32_t* counter )
+#define FLAG_SPECULAR 1u
+#define FLAG_INSIDE 2u
+#define META_SLOT_MASK 0x3FFFFFFFu
+
+// ---- queue append.  One device-scope atomic on a single word retires at ~88 per microsecond on this chip, so a
+// per-wave atomic (half a million waves per bounce) is the bottleneck of a wavefront path tracer; here a whole
+// 1024-thread block (16 waves) reserves its entries with ONE atomic per queue: ballot + mbcnt prefix inside the wave,
+// a 16-entry scan in LDS across waves. ----------------------------------------------------------------------------
+template <int NQ>
+__device__ __forceinline__ void block_append( const bool ( &push )[NQ], uint32_t* const ( &counters )[NQ], uint32_t ( &idx )[NQ], uint32_t* lds /* NQ * 16 */ )
 {
-	const unsigned long long mask = __ballot( push );
-	if (mask == 0) return 0;
-	const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
-	uint32_t base = 0;
-	const int leader = __ffsll( (long long)mask ) - 1;
-	if ((int)( threadIdx.x & 63 ) == leader) base = atomicAdd( counter, (uint32_t)__popcll( mask ) );
-	base = __shfl( base, leader, 64 );
-	return base + rank;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	uint32_t rank[NQ];
+#pragma unroll
+	for (int q = 0; q < NQ; q++)
+	{
+		const unsigned long long mask = __ballot( push[q] );
+		rank[q] = __builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0 ) );
+		if (lane == 0) lds[q * 16 + wave] = (uint32_t)__popcll( mask );
+	}
+	__syncthreads();
+	if (threadIdx.x < NQ)
+	{
+		const int q = threadIdx.x;
+		uint32_t total = 0;
+		for (int w = 0; w < nw; w++) { const uint32_t c = lds[q * 16 + w]; lds[q * 16 + w] = total; total += c; }
+		const uint32_t base = total ? atomicAdd( counters[q], total ) : 0u;
+		for (int w = 0; w < nw; w++) lds[q * 16 + w] += base;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < NQ; q++) idx[q] = lds[q * 16 + wave] + rank[q];
 }
 __device__ __forceinline__ void wave_add64( unsigned long long v, unsigned long long* dst )
 {
@@ -83,140 +108,83 @@ __device__ __forceinline__ void primary_ray( const CamProp& cam, float x, float 
 	D = normalize3( P - O );
 }
 
-// ---- extend: closest hit ---------------------------------------------------------------------------------------
-template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__( BLOCK ) void k_extend( DScene s, PathState st, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
-	uint32_t n_primary, CamProp cam, int W, int H, float invW, float invH, DevCounters* ctr )
+// The part of Scene::FindNearest that needs no BVH walk, done by the kernel that CREATES the ray while it still has it
+// in registers (every lane busy): quads[0], cubes[0], planes (scene.h:361-362, bvh.h:498-502), the reciprocal
+// direction and the root box test.  Returns true when the ray has to walk the BVH.
+__device__ __forceinline__ bool begin_closest( const DScene& s, f3 O, f3 D, RayHit& h )
 {
-	extern __shared__ uint32_t lds_stack[];
-	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-	const uint32_t n = PRIMARY ? n_primary : *count_ptr;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
-	if (i < n)
-	{
-		uint32_t slot;
-		f3 O, D;
-		if (PRIMARY)
-		{
-			slot = i;
-			const uint32_t p = i % (uint32_t)( W * H );
-			primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
-		}
-		else
-		{
-			slot = queue[i];
-			O = mk3( st.o_t[slot] ), D = mk3( st.d_h[slot] );
-		}
-		RayHit h; h.t = 1e34f, h.obj = -1, h.pos = -1;
-		find_nearest<COUNT>( s, O, D, h, lds_stack + threadIdx.x, BLOCK, tc );
-		if (PRIMARY)
-		{
-			st.o_t[slot] = make_float4( O.x, O.y, O.z, h.t );
-			st.d_h[slot] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
-		}
-		else
-		{
-			st.o_t[slot].w = h.t;
-			st.d_h[slot].w = __int_as_float( h.obj );
-		}
-	}
-	if (COUNT)
-	{
-		wave_add64( tc.pairs, &ctr->extend_pairs );
-		wave_add64( tc.prims, &ctr->extend_prims );
-	}
-	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->extend_rays, (unsigned long long)n );
+	h.t = 1e34f, h.obj = -1, h.pos = -1;
+	isect_analytic( s, O, D, h );
+	if (s.n_bvh_prims == 0) return false;
+	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	return ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
+}
+// Same for Scene::IsOccluded (scene.h:369-379): quad and cube with the shrinking ray.t, then the planes with early out.
+__device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tmaxRay, bool& occluded, bool& walk )
+{
+	RayHit h; h.t = tmaxRay, h.obj = -1, h.pos = -1;
+	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
+	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
+	for (int k = 0; k < s.n_planes && h.obj == -1; k++) isect_plane( s, k, O, D, h );
+	occluded = h.obj != -1, walk = false;
+	if (occluded || s.n_bvh_prims == 0) return;
+	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	walk = ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
 }
 
-// ---- two-step traversal: coherent setup, then persistent BVH walk with lane refill ---------------------------------
-// rocprof of the one-ray-per-thread kernels showed 5 % of VALU lane-cycles active on bounce rays: most rays never
-// enter the BVH (they hit a wall, the light or nothing) and sit idle in a wave until its longest ray is done.
-//   k_setup  one ray per lane, every lane busy: ray generation / queue read, the analytic primitives of
-//            Scene::FindNearest / IsOccluded (quad, cube, planes), reciprocal direction, root box test.  Rays that do
-//            not reach the BVH are finished here; the others are appended (ballot + prefix, one atomic per wave) to the
-//            bounce's traversal queue.
-//   k_trace  a fixed number of resident waves pull from that queue; whenever `refill` lanes of a wave are idle they
-//            get new rays (one atomic per refill), so lanes stay busy although traversal lengths differ widely.
-// Per-ray arithmetic is the same as in k_extend / k_connect, so results are identical.
-template <bool ANY, bool PRIMARY>
-__global__ __launch_bounds__( BLOCK ) void k_setup( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr,
-	uint32_t n_primary, CamProp cam, int W, int H, float invW, float invH, DevCounters* ctr, uint32_t* __restrict__ tq, uint32_t* tq_count )
+// ---- ray generation (bounce 0): camera ray, per-(pixel, sample) rng state, analytic part of FindNearest --------------
+__global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, float4* __restrict__ E, uint32_t N, CamProp cam, int W, int H, float invW, float invH,
+	const uint32_t* __restrict__ seeds, int sample_begin, int sample_stride, uint32_t* __restrict__ wq, DevCounters* ctr )
 {
-	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-	const uint32_t n = PRIMARY ? n_primary : *count_ptr;
+	__shared__ uint32_t lds[16];
+	const uint32_t i = blockIdx.x * SBLOCK + threadIdx.x;
 	bool walk = false;
-	uint32_t entry = 0;
-	if (i < n)
+	if (i < N)
 	{
+		const uint32_t WH = (uint32_t)( W * H ), p = i % WH, sidx = (uint32_t)sample_begin + ( i / WH ) * (uint32_t)sample_stride;
 		f3 O, D;
-		uint32_t slot;
-		RayHit h; h.obj = -1, h.pos = -1;
-		if (ANY)
-		{
-			const float4 ot = sq.o_t[i], ds = sq.d_s[i];
-			O = mk3( ot ), D = mk3( ds ), h.t = ot.w, slot = __float_as_uint( ds.w ), entry = i;
-		}
-		else if (PRIMARY)
-		{
-			slot = i, entry = i;
-			const uint32_t p = i % (uint32_t)( W * H );
-			primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
-			h.t = 1e34f;
-		}
-		else
-		{
-			slot = queue[i], entry = slot;
-			O = mk3( st.o_t[slot] ), D = mk3( st.d_h[slot] ), h.t = 1e34f;
-		}
-		bool occluded = false;
-		if (ANY)
-		{
-			if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
-			if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
-			for (int k = 0; k < s.n_planes && h.obj == -1; k++) isect_plane( s, k, O, D, h );
-			occluded = h.obj != -1;
-		}
-		else isect_analytic( s, O, D, h );
-		if (!occluded && s.n_bvh_prims > 0)
-		{
-			const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
-			const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-			walk = ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
-		}
-		if (ANY)
-		{
-			if (!occluded && !walk)
-			{
-				const float4 c = sq.c[i];
-				float4 e = st.E_f[slot];
-				e.x += c.x, e.y += c.y, e.z += c.z;
-				st.E_f[slot] = e;
-			}
-		}
-		else if (PRIMARY)
-		{
-			st.o_t[slot] = make_float4( O.x, O.y, O.z, h.t );
-			st.d_h[slot] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
-		}
-		else
-		{
-			st.o_t[slot].w = h.t;
-			st.d_h[slot].w = __int_as_float( h.obj );
-		}
+		primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
+		RayHit h;
+		walk = begin_closest( s, O, D, h );
+		st.o_t[i] = make_float4( O.x, O.y, O.z, h.t );
+		st.d_h[i] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+		st.T_s[i] = make_float4( 1, 1, 1, __uint_as_float( sample_seed( seeds[p], sidx ) ) );
+		st.meta[i] = i | ( FLAG_SPECULAR << 30 );
+		E[i] = make_float4( 0, 0, 0, 0 );
 	}
-	const uint32_t qi = wave_append( walk, tq_count );
-	if (walk) tq[qi] = entry;
-	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( ANY ? &ctr->shadow_rays : &ctr->extend_rays, (unsigned long long)n );
+	const bool push[1] = { walk };
+	uint32_t* const counters[1] = { &ctr->n_walk[0] };
+	uint32_t idx[1];
+	block_append<1>( push, counters, idx, lds );
+	if (walk) wq[idx[0]] = i;
+	if (i == 0) ctr->n_state[0] = N;
 }
 
+// ---- BVH walk: persistent waves with lane refill -----------------------------------------------------------------
+// Most rays of a bounce never enter the BVH (they end on a wall, the light or nothing) and the ones that do have very
+// different traversal lengths, so one-ray-per-thread launches leave most lanes of a wave idle.  Here the rays that
+// passed the root box test (queued by the kernel that created them) are pulled by a fixed number of resident waves:
+// a wave reserves a CHUNK of the queue with one atomic, and whenever `refill` of its lanes are idle they take the next
+// rays of the chunk, so lanes stay busy and the pool counter sees one atomic per few hundred rays.
+//   ANY = false: closest hit (IntersectBVH, bvh.h:507-530); entry = index into the path state; the analytic hit found
+//                by the creating kernel is the starting t.
+//   ANY = true:  any hit (IntersectBVHShadowRay, bvh.h:640-688) over the shadow queue; E[slot] += contribution when
+//                nothing is hit (renderer.cpp:339-344).
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ tq, const uint32_t* __restrict__ count_ptr,
-	DevCounters* ctr, uint32_t* pool, int refill )
+__global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ wq,
+	const uint32_t* __restrict__ count_ptr, const uint32_t* __restrict__ rays_ptr, DevCounters* ctr, uint32_t* pool, int refill )
 {
 	extern __shared__ uint32_t lds_stack[];
 	uint32_t* stack = lds_stack + threadIdx.x;
 	const uint32_t n = *count_ptr;
 	const int lane = threadIdx.x & 63;
+	// chunk: large enough that the pool counter is not the bottleneck, small enough that the last chunks balance
+	const uint32_t waves = gridDim.x * ( BLOCK / 64 );
+	uint32_t chunk = n / ( waves * 4u );
+	chunk = chunk < 64u ? 64u : ( chunk > 512u ? 512u : chunk );
+	uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
 	bool has = false, exhausted = false, inexact = false, occluded = false;
 	uint32_t cur = RT_DONE, entry = 0, slot = 0;
 	int sp = 0;
@@ -229,28 +197,38 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 		const int nIdle = __popcll( idle );
 		if (!exhausted && nIdle >= refill)
 		{
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd( pool, (uint32_t)nIdle );
-			base = __shfl( base, 0, 64 );
-			if (base + (uint32_t)nIdle >= n) exhausted = true;
-			const uint32_t my = base + __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0 ) );
-			if (!has && my < n)
+			if (chunk_next == chunk_end)
 			{
-				entry = tq[my], has = true, sp = 0, occluded = false, h.pos = -1;
-				if (ANY)
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd( pool, chunk );
+				base = __shfl( base, 0, 64 );
+				if (base >= n) exhausted = true, chunk_next = chunk_end = 0;
+				else chunk_next = base, chunk_end = ( n - base < chunk ) ? n : base + chunk;
+			}
+			if (!exhausted)
+			{
+				const uint32_t my = chunk_next + __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0 ) );
+				if (!has && my < chunk_end)
 				{
-					const float4 ot = sq.o_t[entry], ds = sq.d_s[entry];
-					O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
+					has = true, sp = 0, occluded = false, h.pos = -1;
+					if (ANY)
+					{
+						entry = my;
+						const float4 ot = sq.o_t[entry], ds = sq.d_s[entry];
+						O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
+					}
+					else
+					{
+						entry = wq[my];
+						const float4 ot = st.o_t[entry], dh = st.d_h[entry];
+						O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far
+					}
+					rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+					inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+					cur = s.root_ref; // the root box test passed in the creating kernel
 				}
-				else
-				{
-					slot = entry;
-					const float4 ot = st.o_t[slot], dh = st.d_h[slot];
-					O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far (k_setup)
-				}
-				rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
-				inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-				cur = s.root_ref; // the root box test passed in k_setup
+				chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
+				if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
 			}
 		}
 		if (__ballot( has ) == 0)
@@ -285,15 +263,15 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 				if (!occluded)
 				{
 					const float4 c = sq.c[entry];
-					float4 e = st.E_f[slot];
-					e.x += c.x, e.y += c.y, e.z += c.z;
-					st.E_f[slot] = e;
+					float4 e = E[slot];
+					e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
+					E[slot] = e;
 				}
 			}
 			else if (h.pos >= 0) // a BVH primitive beat the analytic hit
 			{
-				st.o_t[slot].w = h.t;
-				st.d_h[slot].w = __int_as_float( h.obj );
+				st.o_t[entry].w = h.t;
+				st.d_h[entry].w = __int_as_float( h.obj );
 			}
 			has = false, inexact = false;
 		}
@@ -303,43 +281,36 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 		wave_add64( tc.pairs, ANY ? &ctr->shadow_pairs : &ctr->extend_pairs );
 		wave_add64( tc.prims, ANY ? &ctr->shadow_prims : &ctr->extend_prims );
 	}
+	// every closest-hit ray of the bounce counts as an extend ray, whether it had to walk the BVH or not
+	if (!ANY && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->extend_rays, (unsigned long long)*rays_ptr );
 }
 
-// ---- shade: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361) -----------------------------
-#define FLAG_SPECULAR 1u
-#define FLAG_INSIDE 2u
-
-template <bool PRIMARY>
-__global__ __launch_bounds__( BLOCK ) void k_shade( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
-	const uint32_t* __restrict__ count_ptr, uint32_t n_primary, const uint32_t* __restrict__ seeds, int WH, int sample_begin, int sample_stride,
-	uint32_t* next_count, uint32_t* shadow_count )
+// ---- shade: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361), fused with the creation of the next
+// ray and of the shadow ray: their analytic intersections and root box tests run here, so that a bounce is
+//   k_trace<closest>  ->  k_shade  ->  k_trace<any>
+// and rays that never reach the BVH cost no queue traffic at all. ------------------------------------------------------
+__global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ n_in,
+	uint32_t* n_out, uint32_t* __restrict__ wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {
-	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-	const uint32_t n = PRIMARY ? n_primary : *count_ptr;
-	bool push_next = false, push_shadow = false;
-	uint32_t slot = 0;
-	f3 newO, newD, shO, shD, contrib;
+	__shared__ uint32_t lds[3 * 16 + 1];
+	if (threadIdx.x == 0) lds[48] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * SBLOCK + threadIdx.x;
+	const uint32_t n = *n_in;
+	bool push_next = false, walk_next = false, shadow_any = false, push_shadow = false;
+	uint32_t slot = 0, flags = 0, rng = 0;
+	f3 newO, newD, shO, shD, contrib, T;
 	float shT = 0;
-	f3 T, E;
-	uint32_t rng = 0, flags = 0;
+	RayHit nh; nh.t = 1e34f, nh.obj = -1, nh.pos = -1;
 	if (i < n)
 	{
-		slot = PRIMARY ? i : queue_in[i];
-		const float4 ot = st.o_t[slot], dh = st.d_h[slot];
+		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
+		const uint32_t meta = in.meta[i];
+		slot = meta & META_SLOT_MASK, flags = meta >> 30;
 		const f3 O = mk3( ot ), D = mk3( dh );
 		const float t = ot.w;
 		const int obj = __float_as_int( dh.w );
-		if (PRIMARY)
-		{
-			const uint32_t p = slot % (uint32_t)WH, sidx = (uint32_t)sample_begin + ( slot / (uint32_t)WH ) * (uint32_t)sample_stride;
-			T = mk3( 1, 1, 1 ), E = mk3( 0, 0, 0 ), flags = FLAG_SPECULAR, rng = sample_seed( seeds[p], sidx );
-		}
-		else
-		{
-			const float4 ts = st.T_s[slot], ef = st.E_f[slot];
-			T = mk3( ts ), rng = __float_as_uint( ts.w ), E = mk3( ef ), flags = __float_as_uint( ef.w );
-		}
-		bool writeE = PRIMARY;
+		T = mk3( ts ), rng = __float_as_uint( ts.w );
 		if (obj != -1)
 		{
 			const f3 I = O + t * D;
@@ -349,7 +320,13 @@ __global__ __launch_bounds__( BLOCK ) void k_shade( DScene s, PathState st, Shad
 			const int type = a.mat->type;
 			if (type == RTMI_LIGHT)
 			{
-				if (flags & FLAG_SPECULAR) E = E + T * mk3( s.light_emission ), writeE = true; // renderer.cpp:262-263
+				if (flags & FLAG_SPECULAR) // renderer.cpp:262-263: E + T * emission
+				{
+					const f3 add = T * mk3( s.light_emission );
+					float4 e = E[slot];
+					e.x = e.x + add.x, e.y = e.y + add.y, e.z = e.z + add.z;
+					E[slot] = e;
+				}
 			}
 			else if (type == RTMI_MIRROR) // renderer.cpp:266-271
 			{
@@ -409,7 +386,7 @@ __global__ __launch_bounds__( BLOCK ) void k_shade( DScene s, PathState st, Shad
 					const float lightPDF = 1.0f / solidAngle;
 					contrib = T * ( dot3( N, L ) / lightPDF ) * BRDF * mk3( s.light_emission );
 					shO = I + L * 0.001f, shD = L, shT = dist - 2.0f * 0.001f;
-					push_shadow = true;
+					shadow_any = true;
 				}
 				// Russian roulette, renderer.cpp:347-352 (template clamp = fmaxf(a, fminf(f, b)) with ternaries)
 				float p = smax( a.albedo.z, smax( a.albedo.x, a.albedo.y ) );
@@ -436,66 +413,59 @@ __global__ __launch_bounds__( BLOCK ) void k_shade( DScene s, PathState st, Shad
 				}
 			}
 		}
-		if (push_next)
+		// the rays created here start their life here: everything of FindNearest / IsOccluded before the BVH walk
+		if (push_next) walk_next = begin_closest( s, newO, newD, nh );
+		if (shadow_any)
 		{
-			st.o_t[slot] = make_float4( newO.x, newO.y, newO.z, 1e34f );
-			st.d_h[slot] = make_float4( newD.x, newD.y, newD.z, __int_as_float( -1 ) );
-			st.T_s[slot] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+			bool occluded;
+			begin_any( s, shO, shD, shT, occluded, push_shadow );
+			if (!occluded && !push_shadow) // unoccluded without a walk: E += contribution now (renderer.cpp:343)
+			{
+				float4 e = E[slot];
+				e.x += contrib.x, e.y += contrib.y, e.z += contrib.z;
+				E[slot] = e;
+			}
 		}
-		if (push_next || writeE) st.E_f[slot] = make_float4( E.x, E.y, E.z, __uint_as_float( flags ) );
 	}
-	const uint32_t qi = wave_append( push_next, next_count );
-	if (push_next) queue_out[qi] = slot;
-	const uint32_t si = wave_append( push_shadow, shadow_count );
+	{
+		const unsigned long long m = __ballot( shadow_any );
+		if (( threadIdx.x & 63 ) == 0 && m) atomicAdd( &lds[48], (uint32_t)__popcll( m ) );
+	}
+	const bool push[3] = { push_next, walk_next, push_shadow };
+	uint32_t* const counters[3] = { n_out, n_walk_out, n_shadow };
+	uint32_t idx[3];
+	block_append<3>( push, counters, idx, lds );
+	if (push_next)
+	{
+		const uint32_t j = idx[0];
+		out.o_t[j] = make_float4( newO.x, newO.y, newO.z, nh.t );
+		out.d_h[j] = make_float4( newD.x, newD.y, newD.z, __int_as_float( nh.obj ) );
+		out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+		out.meta[j] = slot | ( flags << 30 );
+		if (walk_next) wq_out[idx[1]] = j;
+	}
 	if (push_shadow)
 	{
+		const uint32_t si = idx[2];
 		sq.o_t[si] = make_float4( shO.x, shO.y, shO.z, shT );
 		sq.d_s[si] = make_float4( shD.x, shD.y, shD.z, __uint_as_float( slot ) );
 		sq.c[si] = make_float4( contrib.x, contrib.y, contrib.z, 0 );
 	}
+	if (threadIdx.x == 0 && lds[48]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[48] );
 }
 
-// ---- connect: any hit over the shadow queue (renderer.cpp:339-344) ------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__( BLOCK ) void k_connect( DScene s, PathState st, ShadowQueue sq, const uint32_t* __restrict__ count_ptr, DevCounters* ctr )
-{
-	extern __shared__ uint32_t lds_stack[];
-	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-	const uint32_t n = *count_ptr;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
-	if (i < n)
-	{
-		const float4 ot = sq.o_t[i], ds = sq.d_s[i];
-		const bool occ = is_occluded<COUNT>( s, mk3( ot ), mk3( ds ), ot.w, lds_stack + threadIdx.x, BLOCK, tc );
-		if (!occ)
-		{
-			const uint32_t slot = __float_as_uint( ds.w );
-			const float4 c = sq.c[i];
-			float4 e = st.E_f[slot];
-			e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
-			st.E_f[slot] = e;
-		}
-	}
-	if (COUNT)
-	{
-		wave_add64( tc.pairs, &ctr->shadow_pairs );
-		wave_add64( tc.prims, &ctr->shadow_prims );
-	}
-	if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->shadow_rays, (unsigned long long)n );
-}
-
-// the shadow count of a bounce is consumed by k_connect of the same bounce; reset it for the next one
-__global__ void k_reset_shadow( DevCounters* ctr, int which_next ) { ctr->shadow = 0; ctr->next[which_next] = 0; ctr->pool_extend = 0; ctr->pool_connect = 0; ctr->tq_extend = 0; ctr->tq_connect = 0; }
+// end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
+__global__ void k_next_bounce( DevCounters* ctr, int consumed ) { ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow = 0, ctr->pool_extend = 0, ctr->pool_connect = 0; }
 
 // ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
-__global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E_f, int WH, int S )
+__global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E, int WH, int S )
 {
 	const int p = blockIdx.x * BLOCK + threadIdx.x;
 	if (p >= WH) return;
 	float4 a = acc[p];
 	for (int k = 0; k < S; k++)
 	{
-		const float4 e = E_f[(size_t)k * WH + p];
+		const float4 e = E[(size_t)k * WH + p];
 		a.x += e.x, a.y += e.y, a.z += e.z, a.w += 0.0f;
 	}
 	acc[p] = a;
@@ -757,8 +727,7 @@ struct rtmi_ctx
 	DScene ds = {};
 	std::vector<void*> scene_allocs;
 	int stack_depth = 8;
-	bool persistent = true; // k_trace (persistent waves + lane refill) instead of one ray per thread
-	int refill = 16;        // refill a wave when at least this many lanes are idle
+	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
 	int n_cus = 256;
 	CamProp cam = {};
@@ -768,10 +737,10 @@ struct rtmi_ctx
 	uint32_t* pixels = 0, *pixels2 = 0, *gamma_lut = 0;
 	// path tracing state, sized for `batch` samples in flight
 	int batch = 0;
-	PathState st = {};
+	PathState st[2] = {};       // queue-ordered path state, ping-pong
 	ShadowQueue sq = {};
-	uint32_t* queue[2] = { 0, 0 };
-	uint32_t* tq[2] = { 0, 0 }; // traversal queues: [0] closest hit, [1] any hit
+	float4* E = 0;              // radiance estimate per slot (sample_in_batch * W*H + pixel)
+	uint32_t* wq[2] = { 0, 0 }; // per state set: entries that walk the BVH
 	DevCounters* ctr = 0;
 	uint32_t* host_counts = 0; // pinned ring of read-back queue lengths
 	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
@@ -849,19 +818,23 @@ static void free_scene( rtmi_ctx* c )
 }
 static void free_batch( rtmi_ctx* c )
 {
-	void* ps[] = { c->st.o_t, c->st.d_h, c->st.T_s, c->st.E_f, c->sq.o_t, c->sq.d_s, c->sq.c, c->queue[0], c->queue[1], c->tq[0], c->tq[1] };
+	void* ps[] = { c->st[0].o_t, c->st[0].d_h, c->st[0].T_s, c->st[0].meta, c->st[1].o_t, c->st[1].d_h, c->st[1].T_s, c->st[1].meta,
+		c->sq.o_t, c->sq.d_s, c->sq.c, c->E, c->wq[0], c->wq[1] };
 	for (void* p : ps) if (p) (void)hipFree( p );
-	c->st = PathState{}, c->sq = ShadowQueue{}, c->queue[0] = c->queue[1] = 0, c->tq[0] = c->tq[1] = 0, c->batch = 0;
+	c->st[0] = c->st[1] = PathState{}, c->sq = ShadowQueue{}, c->E = 0, c->wq[0] = c->wq[1] = 0, c->batch = 0;
 }
+// 176 bytes of queue state per path in flight: 2 x 52 B path state, 16 B E, 48 B shadow ray, 2 x 4 B walk index
 static int ensure_batch( rtmi_ctx* c, int S )
 {
 	if (c->batch >= S) return RTMI_OK;
 	free_batch( c );
 	const size_t n = (size_t)S * c->W * c->H;
-	int r;
-	if (( r = dev_alloc( c, &c->st.o_t, n ) ) || ( r = dev_alloc( c, &c->st.d_h, n ) ) || ( r = dev_alloc( c, &c->st.T_s, n ) ) || ( r = dev_alloc( c, &c->st.E_f, n ) ) ||
-		( r = dev_alloc( c, &c->sq.o_t, n ) ) || ( r = dev_alloc( c, &c->sq.d_s, n ) ) || ( r = dev_alloc( c, &c->sq.c, n ) ) ||
-		( r = dev_alloc( c, &c->queue[0], n ) ) || ( r = dev_alloc( c, &c->queue[1], n ) ) || ( r = dev_alloc( c, &c->tq[0], n ) ) || ( r = dev_alloc( c, &c->tq[1], n ) )) { free_batch( c ); return r; }
+	int r = RTMI_OK;
+	for (int k = 0; k < 2 && !r; k++)
+		( r = dev_alloc( c, &c->st[k].o_t, n ) ) || ( r = dev_alloc( c, &c->st[k].d_h, n ) ) || ( r = dev_alloc( c, &c->st[k].T_s, n ) ) || ( r = dev_alloc( c, &c->st[k].meta, n ) ) ||
+			( r = dev_alloc( c, &c->wq[k], n ) );
+	if (!r) ( r = dev_alloc( c, &c->sq.o_t, n ) ) || ( r = dev_alloc( c, &c->sq.d_s, n ) ) || ( r = dev_alloc( c, &c->sq.c, n ) ) || ( r = dev_alloc( c, &c->E, n ) );
+	if (r) { free_batch( c ); return r; }
 	c->batch = S;
 	return RTMI_OK;
 }
@@ -887,9 +860,7 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties( &prop, device_id ) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-		const char* e = getenv( "RTMI_PERSISTENT" );
-		if (e) c->persistent = atoi( e ) != 0;
-		e = getenv( "RTMI_REFILL" );
+		const char* e = getenv( "RTMI_REFILL" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= 64) c->refill = atoi( e );
 	}
 	const size_t n = (size_t)width * height;
@@ -1144,66 +1115,61 @@ int rtmi_set_accumulator( rtmi_ctx* c, void* p )
 
 static size_t stack_bytes( rtmi_ctx* c ) { return (size_t)c->stack_depth * BLOCK * sizeof( uint32_t ); }
 
-// one batch of S samples: bounce 0 over all S*W*H slots, then queue-driven bounces until the queue is empty
+static inline int nsblocks( size_t n ) { return (int)( ( n + SBLOCK - 1 ) / SBLOCK ); }
+// persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need
+static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); }
+
+static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper )
+{
+	const size_t lds = stack_bytes( c );
+	hipStream_t s = c->stream;
+	DevCounters* ctr = c->ctr;
+	const uint32_t* count = any ? &ctr->n_shadow : &ctr->n_walk[set];
+	uint32_t* pool = any ? &ctr->pool_connect : &ctr->pool_extend;
+	ScopedTimer t( c, any ? 2 : 0 );
+	if (any)
+	{
+		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
+		else hipLaunchKernelGGL( ( k_trace<true, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
+	}
+	else
+	{
+		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<false, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
+		else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
+	}
+}
+static void launch_primary( rtmi_ctx* c, uint32_t N, int sample_begin, int stride )
+{
+	ScopedTimer t( c, 1 );
+	hipLaunchKernelGGL( k_primary, dim3( nsblocks( N ) ), dim3( SBLOCK ), 0, c->stream, c->ds, c->st[0], c->E, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
+		c->seeds, sample_begin, stride, c->wq[0], c->ctr );
+}
+
+// one batch of S samples: ray generation over all S*W*H slots, then queue-driven bounces until the queue is empty
 static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 {
 	const int WH = c->W * c->H;
 	const uint32_t N = (uint32_t)( (size_t)S * WH );
-	const float invW = 1.0f / c->W, invH = 1.0f / c->H; // camera.h:31-32
-	const size_t lds = stack_bytes( c );
 	hipStream_t s = c->stream;
-	HIPCHK( hipMemsetAsync( c->ctr, 0, 32, s ) ); // next[2], shadow, pools, pad
-	const bool cn = c->count_nodes;
-	const int refill = c->refill;
-	// persistent launches: as many waves as stay resident (LDS stack bound), never more than the rays need
-	auto pgrid = [&]( uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); };
-	auto extend = [&]( bool primary, uint32_t rays, const uint32_t* queue, const uint32_t* count_ptr ) {
-		ScopedTimer t( c, 0 );
-		if (c->persistent)
-		{
-			if (primary) hipLaunchKernelGGL( ( k_setup<false, true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, queue, count_ptr, rays, c->cam, c->W, c->H, invW, invH, c->ctr, c->tq[0], &c->ctr->tq_extend );
-			else hipLaunchKernelGGL( ( k_setup<false, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, queue, count_ptr, 0u, c->cam, c->W, c->H, invW, invH, c->ctr, c->tq[0], &c->ctr->tq_extend );
-			if (cn) hipLaunchKernelGGL( ( k_trace<false, true> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[0], &c->ctr->tq_extend, c->ctr, &c->ctr->pool_extend, refill );
-			else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[0], &c->ctr->tq_extend, c->ctr, &c->ctr->pool_extend, refill );
-		}
-		else if (primary)
-		{
-			if (cn) hipLaunchKernelGGL( ( k_extend<true, true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, rays, c->cam, c->W, c->H, invW, invH, c->ctr );
-			else hipLaunchKernelGGL( ( k_extend<true, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, rays, c->cam, c->W, c->H, invW, invH, c->ctr );
-		}
-		else
-		{
-			if (cn) hipLaunchKernelGGL( ( k_extend<false, true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
-			else hipLaunchKernelGGL( ( k_extend<false, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, queue, count_ptr, 0u, c->cam, c->W, c->H, invW, invH, c->ctr );
-		}
-	};
-	auto connect = [&]( uint32_t rays ) {
-		ScopedTimer t( c, 2 );
-		if (c->persistent)
-		{
-			hipLaunchKernelGGL( ( k_setup<true, false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, nullptr, &c->ctr->shadow, 0u, c->cam, c->W, c->H, invW, invH, c->ctr, c->tq[1], &c->ctr->tq_connect );
-			if (cn) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[1], &c->ctr->tq_connect, c->ctr, &c->ctr->pool_connect, refill );
-			else hipLaunchKernelGGL( ( k_trace<true, false> ), pgrid( rays ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, c->tq[1], &c->ctr->tq_connect, c->ctr, &c->ctr->pool_connect, refill );
-		}
-		else if (cn) hipLaunchKernelGGL( ( k_connect<true> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
-		else hipLaunchKernelGGL( ( k_connect<false> ), dim3( nblocks( rays ) ), dim3( BLOCK ), lds, s, c->ds, c->st, c->sq, &c->ctr->shadow, c->ctr );
-	};
-	extend( true, N, nullptr, nullptr );
-	{
-		ScopedTimer t( c, 1 );
-		hipLaunchKernelGGL( ( k_shade<true> ), dim3( nblocks( N ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, nullptr, c->queue[0], nullptr, N, c->seeds, WH, sample_begin, stride,
-			&c->ctr->next[0], &c->ctr->shadow );
-	}
+	DevCounters* ctr = c->ctr;
+	HIPCHK( hipMemsetAsync( ctr, 0, 32, s ) ); // queue lengths and pools
+	launch_primary( c, N, sample_begin, stride );
 	c->stats.primary_samples += N;
-	uint32_t upper = N; // upper bound of the current bounce queue length (lengths never grow)
-	int cur = 0;        // queue[cur] / next[cur] feed the next extend
+	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
+	int cur = 0;        // state set holding the rays of this bounce
 	for (int bounce = 0;; bounce++)
 	{
-		connect( upper ); // this bounce's shadow rays (at most `upper` of them)
+		launch_trace( c, false, cur, upper );
+		{
+			ScopedTimer t( c, 1 );
+			hipLaunchKernelGGL( k_shade, dim3( nsblocks( upper ) ), dim3( SBLOCK ), 0, s, c->ds, c->st[cur], c->st[cur ^ 1], c->sq, c->E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
+				c->wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow, ctr );
+		}
+		launch_trace( c, true, cur, upper ); // this bounce's shadow rays (at most `upper` of them)
 		c->stats.bounce_launches++;
-		// read back the length of the queue that feeds bounce+1, two iterations late
+		// read back the length of the queue that feeds bounce+1; it is looked at two iterations later
 		const int slot = bounce & 3;
-		HIPCHK( hipMemcpyAsync( &c->host_counts[slot], &c->ctr->next[cur], 4, hipMemcpyDeviceToHost, s ) );
+		HIPCHK( hipMemcpyAsync( &c->host_counts[slot], &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost, s ) );
 		HIPCHK( hipEventRecord( c->count_ev[slot], s ) );
 		if (bounce >= 2)
 		{
@@ -1212,18 +1178,12 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 			upper = std::min( upper, c->host_counts[old] );
 		}
 		if (upper == 0) break;
-		hipLaunchKernelGGL( k_reset_shadow, dim3( 1 ), dim3( 1 ), 0, s, c->ctr, cur ^ 1 );
-		extend( false, upper, c->queue[cur], &c->ctr->next[cur] );
-		{
-			ScopedTimer t( c, 1 );
-			hipLaunchKernelGGL( ( k_shade<false> ), dim3( nblocks( upper ) ), dim3( BLOCK ), 0, s, c->ds, c->st, c->sq, c->queue[cur], c->queue[cur ^ 1], &c->ctr->next[cur], 0u, c->seeds, WH,
-				sample_begin, stride, &c->ctr->next[cur ^ 1], &c->ctr->shadow );
-		}
+		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
 		cur ^= 1;
 	}
 	{
 		ScopedTimer t( c, 3 );
-		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, s, c->accum, c->st.E_f, WH, S );
+		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, s, c->accum, c->E, WH, S );
 	}
 	HIPCHK( hipGetLastError() );
 	return RTMI_OK;
@@ -1293,14 +1253,15 @@ int rtmi_trace_primary( rtmi_ctx* c, int32_t* obj_out, float* t_out )
 	int* dobj = 0; float* dt = 0;
 	if (( r = dev_alloc( c, &dobj, WH ) )) return r;
 	if (( r = dev_alloc( c, &dt, WH ) )) { (void)hipFree( dobj ); return r; }
-	hipLaunchKernelGGL( ( k_extend<true, false> ), dim3( nblocks( WH ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, c->st, nullptr, nullptr, (uint32_t)WH, c->cam, c->W, c->H,
-		1.0f / c->W, 1.0f / c->H, c->ctr );
-	hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, c->stream, c->st, WH, dobj, dt );
+	hipError_t e0 = hipMemsetAsync( c->ctr, 0, 32, c->stream );
+	launch_primary( c, (uint32_t)WH, 0, 1 );
+	launch_trace( c, false, 0, (uint32_t)WH );
+	hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, c->stream, c->st[0], WH, dobj, dt );
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e3 = hipStreamSynchronize( c->stream );
 	(void)hipFree( dobj ), (void)hipFree( dt );
-	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
+	HIPCHK( e0 ); HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
 	return RTMI_OK;
 }
 

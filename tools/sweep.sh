@@ -1,17 +1,13 @@
 #!/bin/bash
 # tools/sweep.sh -- GPU box: correctness first, then bench variants (one JSON line each in gpurun_out/sweep.log)
+#   tools/sweep.sh "VAR=val VAR2=val" "VAR=val" ...   (each argument is one environment to run bench.py under)
 set -u
-timeout -k 10 300 python -u -m pytest tests/test_gpu_golden.py -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/sweep_tests.log 2>&1 || { tail -30 gpurun_out/sweep_tests.log; exit 1; }
+timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/sweep_tests.log 2>&1 || { tail -40 gpurun_out/sweep_tests.log; exit 1; }
 tail -2 gpurun_out/sweep_tests.log
 : > gpurun_out/sweep.log
-run() { echo "## $*" >> gpurun_out/sweep.log; env "$@" timeout -k 10 300 python -u bench.py --no-cpu-baseline --steps 2 --warmup 1 2>&1 | grep '^{' >> gpurun_out/sweep.log || exit 1; }
-run RTMI_PERSISTENT=0
-run RTMI_PERSISTENT=1 RTMI_REFILL=1
-run RTMI_PERSISTENT=1 RTMI_REFILL=8
-run RTMI_PERSISTENT=1 RTMI_REFILL=16
-run RTMI_PERSISTENT=1 RTMI_REFILL=4
-run RTMI_PERSISTENT=1 RTMI_REFILL=32
-run RTMI_PERSISTENT=1 RTMI_REFILL=64
+run() { echo "## $*" >> gpurun_out/sweep.log; env $* timeout -k 10 300 python -u bench.py --no-cpu-baseline --steps 2 --warmup 1 2>&1 | grep '^{' >> gpurun_out/sweep.log || exit 1; }
+if [ $# -eq 0 ]; then set -- "RTMI_REFILL=16"; fi
+for e in "$@"; do run "$e"; done
 python3 - <<'PY'
 import json
 for l in open('gpurun_out/sweep.log'):
