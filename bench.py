@@ -151,7 +151,8 @@ def main():
                                    "samples split by index over ranks, one RCCL reduce + RGB8 finalize at the end" % (info["triangles"], W, H, spp),
                        "triangles": info["triangles"], "bvh_nodes": info["nodes_used"], "bvh_depth": info["max_depth"], "builder": a.builder,
                        "width": W, "height": H, "spp_per_step": spp, "total_spp": a.steps * spp * world, "parallelism": "sample-split x%d" % world},
-            "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays, "rays_per_path": total_rays / max(1.0, paths),
+            "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays,
+            "extend_walkers": float(st["extend_walkers"]), "shadow_walkers": float(st["shadow_walkers"]), "rays_per_path": total_rays / max(1.0, paths),
             "scene_build_s": build_s,
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": a.traffic_bytes_per_launch, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,

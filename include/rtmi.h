@@ -96,6 +96,8 @@ typedef struct rtmi_stats {
 	uint64_t bounce_launches;   /* extend/shade/connect rounds */
 	double   ms_extend, ms_shade, ms_connect, ms_other; /* hipEvent time per kernel class (profiling mode only) */
 	uint64_t n_extend_launches, n_shade_launches, n_connect_launches;
+	uint64_t extend_walkers;    /* closest-hit rays that passed the root box test and walked the BVH (the rest end in the analytic tests) */
+	uint64_t shadow_walkers;    /* same for any-hit rays */
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,

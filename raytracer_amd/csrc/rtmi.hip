@@ -56,7 +56,7 @@ struct DevCounters // the first 32 bytes are zeroed per render batch
 	uint32_t pool_extend;  // next unclaimed entry of the running k_trace<closest> launch (persistent waves pull chunks from it)
 	uint32_t pool_connect; // same for k_trace<any>
 	uint32_t pad;
-	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims;
+	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers;
 };
 
 #define FLAG_SPECULAR 1u
@@ -185,95 +185,102 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 	uint32_t chunk = n / ( waves * 4u );
 	chunk = chunk < 64u ? 64u : ( chunk > 512u ? 512u : chunk );
 	uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
+	// lane state: !has = empty; has && cur == RT_DONE = finished, waiting to be retired; else walking
 	bool has = false, exhausted = false, inexact = false, occluded = false;
 	uint32_t cur = RT_DONE, entry = 0, slot = 0;
-	int sp = 0;
+	int sp = 0, k = 0; // stack pointer; primitives of the current leaf already tested
 	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), rD = mk3( 0, 0, 1 );
 	RayHit h; h.t = 0, h.obj = -1, h.pos = -1;
 	TravCount tc; tc.pairs = 0, tc.prims = 0;
 	for (;;)
 	{
-		const unsigned long long idle = __ballot( !has );
-		const int nIdle = __popcll( idle );
-		if (!exhausted && nIdle >= refill)
+		const unsigned long long walking = __ballot( has && cur != RT_DONE );
+		if (walking == 0 || 64 - __popcll( walking ) >= refill)
 		{
-			if (chunk_next == chunk_end)
+			// retire finished rays
+			if (has && cur == RT_DONE)
 			{
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd( pool, chunk );
-				base = __shfl( base, 0, 64 );
-				if (base >= n) exhausted = true, chunk_next = chunk_end = 0;
-				else chunk_next = base, chunk_end = ( n - base < chunk ) ? n : base + chunk;
+				if (ANY)
+				{
+					if (!occluded)
+					{
+						const float4 c = sq.c[entry];
+						float4 e = E[slot];
+						e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
+						E[slot] = e;
+					}
+				}
+				else if (h.pos >= 0) // a BVH primitive beat the analytic hit
+				{
+					st.o_t[entry].w = h.t;
+					st.d_h[entry].w = __int_as_float( h.obj );
+				}
+				has = false, inexact = false;
 			}
+			// hand the free lanes new rays
 			if (!exhausted)
 			{
-				const uint32_t my = chunk_next + __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0 ) );
-				if (!has && my < chunk_end)
+				const unsigned long long idle = ~walking;
+				const int nIdle = __popcll( idle );
+				if (chunk_next == chunk_end)
 				{
-					has = true, sp = 0, occluded = false, h.pos = -1;
-					if (ANY)
-					{
-						entry = my;
-						const float4 ot = sq.o_t[entry], ds = sq.d_s[entry];
-						O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
-					}
-					else
-					{
-						entry = wq[my];
-						const float4 ot = st.o_t[entry], dh = st.d_h[entry];
-						O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far
-					}
-					rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
-					inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-					cur = s.root_ref; // the root box test passed in the creating kernel
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd( pool, chunk );
+					base = __shfl( base, 0, 64 );
+					if (base >= n) exhausted = true, chunk_next = chunk_end = 0;
+					else chunk_next = base, chunk_end = ( n - base < chunk ) ? n : base + chunk;
 				}
-				chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
-				if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
+				if (!exhausted)
+				{
+					const uint32_t my = chunk_next + __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0 ) );
+					if (!has && my < chunk_end)
+					{
+						has = true, sp = 0, k = 0, occluded = false, h.pos = -1;
+						if (ANY)
+						{
+							entry = my;
+							const float4 ot = sq.o_t[entry], ds = sq.d_s[entry];
+							O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
+						}
+						else
+						{
+							entry = wq[my];
+							const float4 ot = st.o_t[entry], dh = st.d_h[entry];
+							O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far
+						}
+						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+						inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+						cur = s.root_ref; // the root box test passed in the creating kernel
+					}
+					chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
+					if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
+				}
+			}
+			if (__ballot( has ) == 0)
+			{
+				if (exhausted) break;
+				continue;
 			}
 		}
-		if (__ballot( has ) == 0)
+		// one step per iteration for the majority kind: the lanes at an interior node test its two children, or the
+		// lanes in a leaf test one primitive.  The minority waits; it becomes the majority as the others arrive.
+		const bool atNode = has && !( cur & RT_LEAF ), atLeaf = has && ( cur & RT_LEAF ) && cur != RT_DONE;
+		if (__popcll( __ballot( atNode ) ) >= __popcll( __ballot( atLeaf ) ))
 		{
-			if (exhausted) break;
-			continue;
+			if (__ballot( has && inexact ) != 0)
+			{
+				if (atNode) { if (COUNT) tc.pairs++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+			}
+			else if (atNode) { if (COUNT) tc.pairs++; cur = interior_step<ANY, false>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
 		}
-		if (__ballot( has && inexact ) != 0)
-		{
-			while (!( cur & RT_LEAF )) { if (COUNT) tc.pairs++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
-		}
-		else
-		{
-			while (!( cur & RT_LEAF )) { if (COUNT) tc.pairs++; cur = interior_step<ANY, false>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
-		}
-		if (cur != RT_DONE)
+		else if (atLeaf)
 		{
 			const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
-			bool hit = false;
-			for (int i = 0; i < count && !( ANY && hit ); i++)
-			{
-				if (COUNT) tc.prims++;
-				hit = isect_prim<ANY>( s, first + i, O, D, h );
-			}
-			if (ANY && hit) occluded = true, cur = RT_DONE;
-			else cur = sp > 0 ? stack[--sp * BLOCK] : RT_DONE;
-		}
-		if (has && cur == RT_DONE)
-		{
-			if (ANY)
-			{
-				if (!occluded)
-				{
-					const float4 c = sq.c[entry];
-					float4 e = E[slot];
-					e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
-					E[slot] = e;
-				}
-			}
-			else if (h.pos >= 0) // a BVH primitive beat the analytic hit
-			{
-				st.o_t[entry].w = h.t;
-				st.d_h[entry].w = __int_as_float( h.obj );
-			}
-			has = false, inexact = false;
+			if (COUNT) tc.prims++;
+			const bool hit = isect_prim<ANY>( s, first + k, O, D, h );
+			k++;
+			if (ANY && hit) occluded = true, cur = RT_DONE, k = 0;
+			else if (k == count) k = 0, cur = sp > 0 ? stack[--sp * BLOCK] : RT_DONE;
 		}
 	}
 	if (COUNT)
@@ -282,7 +289,11 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 		wave_add64( tc.prims, ANY ? &ctr->shadow_prims : &ctr->extend_prims );
 	}
 	// every closest-hit ray of the bounce counts as an extend ray, whether it had to walk the BVH or not
-	if (!ANY && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd( &ctr->extend_rays, (unsigned long long)*rays_ptr );
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+	{
+		if (!ANY) atomicAdd( &ctr->extend_rays, (unsigned long long)*rays_ptr );
+		atomicAdd( ANY ? &ctr->shadow_walkers : &ctr->extend_walkers, (unsigned long long)n );
+	}
 }
 
 // ---- shade: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361), fused with the creation of the next
@@ -1078,7 +1089,9 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	{
 		// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 8 (32 waves per CU)
 		const size_t per_block = (size_t)c->stack_depth * BLOCK * sizeof( uint32_t );
-		const int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) );
+		int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) );
+		const char* e = getenv( "RTMI_BLOCKS_PER_CU" );
+		if (e && atoi( e ) >= 1) per_cu = std::min( per_cu, atoi( e ) );
 		c->max_blocks = c->n_cus * per_cu;
 	}
 	return RTMI_OK;
@@ -1197,6 +1210,7 @@ static int fetch_counters( rtmi_ctx* c )
 	c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
 	c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
 	c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
+	c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers;
 	HIPCHK( hipMemsetAsync( c->ctr, 0, sizeof( DevCounters ), c->stream ) );
 	return RTMI_OK;
 }
