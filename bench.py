@@ -59,6 +59,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import api
+    from raytracer_amd import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,8 +91,8 @@ def main():
     spp = a.spp_per_step
 
     def step(i):
-        # global sample index of this rank's k-th sample of step i: (i*spp + k)*world + rank
-        dev.render(api.PATHTRACING, (i * spp) * world + rank, spp, world)
+        # step i covers the global sample indices [i*spp*world, (i+1)*spp*world); this rank renders every world-th one
+        D.render_split(lambda b, n, st: dev.render(api.PATHTRACING, b, n, st), i * spp * world, spp * world, rank, world)
 
     def barrier():
         if world > 1:
@@ -121,7 +122,7 @@ def main():
     for i in range(a.steps):
         step(i)
     if world > 1:
-        dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 16*W*H bytes, once
+        D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once
     pixels = dev.finalize(a.steps * spp * world) if rank == 0 else None
     barrier()
     dt = time.perf_counter() - t0

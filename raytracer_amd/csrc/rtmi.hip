@@ -489,10 +489,12 @@ __global__ __launch_bounds__( BLOCK ) void k_finalize( const float4* __restrict_
 	if (p >= n) return;
 	float4 v = acc[p];
 	if (frames > 0) { const float f = (float)frames; v.x = v.x / f, v.y = v.y / f, v.z = v.z / f; }
-	// std::min(1.0f, x) = (x < 1.0f) ? x : 1.0f ; NaN -> 1.0f
-	const uint32_t r = (uint32_t)( 255.0f * ( v.x < 1.0f ? v.x : 1.0f ) );
-	const uint32_t g = (uint32_t)( 255.0f * ( v.y < 1.0f ? v.y : 1.0f ) );
-	const uint32_t b = (uint32_t)( 255.0f * ( v.z < 1.0f ? v.z : 1.0f ) );
+	// std::min(1.0f, x) = (x < 1.0f) ? x : 1.0f ; NaN -> 1.0f.  Whitted glass can leave slightly negative channels
+	// (Fresnel terms above 1): the reference's (uint) cast of a negative float is the x86-64 one, a truncating
+	// 64-bit conversion whose low 32 bits are kept, so -3.2 becomes 0xFFFFFFFD; restated here, not saturated to 0.
+	const uint32_t r = (uint32_t)(long long)( 255.0f * ( v.x < 1.0f ? v.x : 1.0f ) );
+	const uint32_t g = (uint32_t)(long long)( 255.0f * ( v.y < 1.0f ? v.y : 1.0f ) );
+	const uint32_t b = (uint32_t)(long long)( 255.0f * ( v.z < 1.0f ? v.z : 1.0f ) );
 	out[p] = ( r << 16 ) + ( g << 8 ) + b;
 }
 

@@ -55,7 +55,8 @@ public:
 	BVH& operator=( const BVH& ) = delete;
 	void BuildBVH();       // reference-exact tree
 	void BuildBVHBinned(); // fast builder, same format
-	int NodeCapacity() const { return ( spheres_size + triangles_size ) * 2 + 1; }
+	// N * 2 + 1 nodes as the reference allocates (bvh.h:253), but never fewer than the three fixed nodes 0..2
+	int NodeCapacity() const { const int n = ( spheres_size + triangles_size ) * 2 + 1; return n < 3 ? 3 : n; }
 
 private:
 	void Allocate();

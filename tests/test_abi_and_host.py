@@ -1,0 +1,111 @@
+"""C-ABI shape and host logic (no GPU): librtmi.so loads and exports every symbol include/rtmi.h declares,
+struct layouts agree between the header, ctypes and the C++ host mirror, and error paths that need no device
+return status codes instead of crashing."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rtmi.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtmi_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = api.device_lib()
+    names = declared_functions()
+    assert len(names) >= 20 and "rtmi_render" in names and "rtmi_upload_scene" in names
+    for n in names:
+        assert hasattr(L, n), "librtmi.so does not export " + n
+    assert b"gfx950" in L.rtmi_version()
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof/offsetof as a C compiler sees include/rtmi.h == the ctypes mirrors in raytracer_amd/api.py"""
+    prog = tmp_path / "layout.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rtmi.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                    'sizeof(rtmi_bvh_node),sizeof(rtmi_scene_desc),sizeof(rtmi_postfx),sizeof(rtmi_stats),offsetof(rtmi_scene_desc,nodes),'
+                    'offsetof(rtmi_scene_desc,light_corners),offsetof(rtmi_scene_desc,whitted_intensity),offsetof(rtmi_stats,ms_extend));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(api.BvhNode), C.sizeof(api.SceneDesc), C.sizeof(api.PostFx), C.sizeof(api.Stats), api.SceneDesc.nodes.offset,
+            api.SceneDesc.light_corners.offset, api.SceneDesc.whitted_intensity.offset, api.Stats.ms_extend.offset]
+    assert got == want
+    assert C.sizeof(api.BvhNode) == 32  # GPUBVHNode, bvh.h:11-16
+
+
+def test_null_arguments_are_rejected_without_a_device():
+    L = api.device_lib()
+    assert L.rtmi_create(None, 0, 16, 16) == -1
+    h = C.c_void_p()
+    assert L.rtmi_create(C.byref(h), 0, 0, 16) == -1 and not h.value
+    for f in (L.rtmi_destroy, L.rtmi_synchronize, L.rtmi_reset_accumulator, L.rtmi_reset_stats):
+        assert f(None) == -1
+    assert L.rtmi_render(None, 4, 0, 1, 1, 5, 0) == -1
+    assert L.rtmi_last_error(None) == b"null context"
+
+
+def test_default_scene_conventions(default_scene):
+    """node array conventions of bvh.h:56, 262-274, 380-381 and the object index order of SURVEY A.1"""
+    info = default_scene.info()
+    assert (info["quads"], info["spheres"], info["cubes"], info["planes"], info["triangles"]) == (1, 2, 1, 6, 2901)
+    a = default_scene.desc.arrays()
+    nodes = a["nodes"].view(np.int32)
+    n = info["nodes_used"]
+    left, count = nodes[:n, 6], nodes[:n, 7]
+    interior = np.nonzero(count[2:] == 0)[0] + 2
+    assert np.all(left[interior] >= 3) and np.all((left[interior] - 3) % 2 == 0)  # children in adjacent pairs from node 3
+    children = np.concatenate([left[interior], left[interior] + 1])
+    assert len(np.unique(children)) == len(children) == n - 3  # every node but 0,1,2 is the child of exactly one node
+    leaves = np.nonzero(count[2:] > 0)[0] + 2
+    covered = np.concatenate([np.arange(l, l + c) for l, c in zip(left[leaves], count[leaves])])
+    assert np.array_equal(np.sort(covered), np.arange(info["spheres"] + info["triangles"]))
+    assert np.array_equal(np.sort(a["prim_idx"]), np.arange(info["spheres"] + info["triangles"]))
+    assert list(a["material_type"][:10]) == [api.LIGHT, api.GLASS, api.DIFFUSE, api.DIFFUSE, api.MIRROR] + [api.DIFFUSE] * 5
+
+
+@pytest.mark.parametrize("builder", [api.REFERENCE_SAH, api.BINNED_SAH])
+def test_builders_bound_their_primitives(builder):
+    """every leaf box contains its triangles, every interior box its children, depth within the device stack bound"""
+    s = api.HostScene().make_room()
+    s.add_torus_knot(24, 24, (0, 0, 1.5), api.Material())
+    s.finalize(builder)
+    a, info = s.desc.arrays(), s.info()
+    nodes = a["nodes"][:info["nodes_used"]]
+    f, i = nodes.view(np.float32), nodes.view(np.int32)
+    v = a["tri_verts"][:, :, :3]
+    assert info["max_depth"] <= 64
+    for k in range(2, info["nodes_used"]):
+        lo, hi, left, cnt = f[k, 0:3], f[k, 3:6], i[k, 6], i[k, 7]
+        if cnt > 0:
+            tri = v[a["prim_idx"][left:left + cnt]]
+            assert np.all(tri >= lo - 0) and np.all(tri <= hi + 0), k
+        else:
+            for c in (left, left + 1):
+                assert np.all(f[c, 0:3] >= lo) and np.all(f[c, 3:6] <= hi), k
+
+
+def test_obj_round_trip(tmp_path):
+    """the OBJ path (Scene::LoadObject, scene.h:222-291) keeps file order and bytes: write a knot, load it, compare"""
+    L = api.host_lib()
+    n = 12 * 12 * 2
+    v9 = np.zeros((n, 9), np.float32)
+    assert L.rth_torus_knot(12, 12, 0.42, 0.17, 0.075, 2, 3, 0.0, 0.0, 1.5, v9.ctypes.data) == n
+    path = str(tmp_path / "knot.obj")
+    assert L.rth_write_obj(path.encode(), v9.ctypes.data, n) == 0
+    s = api.HostScene()
+    s.load_obj(path, api.Material())
+    s.finalize()
+    got = s.desc.arrays()["tri_verts"][:, :, :3].reshape(n, 9)
+    assert np.array_equal(got.view(np.uint32), v9.view(np.uint32))

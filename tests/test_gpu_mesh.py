@@ -1,0 +1,245 @@
+"""GPU parity beyond the default scene: mesh scenes built with the product's own builders (the reference's O(n^2)
+builder cannot reach them), checked against the CPU oracle on the same bytes; BASELINE.json's
+full-size config through bit-exact primary hits and size-independent properties; edge cases and error codes of the
+C ABI; the Renderer Init()/Tick() surface.
+
+Bar: hit ids and distances bit-exact; images per-channel RMSE <= 1e-3 (north star), in practice ~1e-7.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api
+from oracle.oracle import Oracle
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def room_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    O = np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1).astype(np.float32)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    D[: n // 50, rng.integers(0, 3)] = 0  # zero direction components
+    return O, D
+
+
+@pytest.mark.parametrize("builder", [api.BINNED_SAH, api.REFERENCE_SAH])
+def test_mesh_scene_matches_oracle(builder):
+    """configs[1]/[2] in small: three knots (diffuse, mirror, glass) in the room, 160x90"""
+    W, H = 160, 90
+    scene = api.mesh_scene(20000, builder)
+    orc = Oracle(scene.desc)
+    cam, seeds = api.default_camera(W, H), api.seed_table(W * H)
+    d = api.Device(W, H)
+    d.upload(scene.desc)
+    d.set_seeds(seeds)
+    obj, t = d.trace_primary()
+    o_obj, o_t = orc.primary_hits(W, H, cam)
+    assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+    assert (obj >= 10).mean() > 0.02  # the knots are in view
+    O, Dr = room_rays(30000, 3)
+    tmax = np.full(len(O), 1e34, np.float32)
+    g_obj, g_t = d.trace_rays(O, Dr, tmax)
+    c_obj, c_t = orc.find_nearest(O, Dr, tmax)
+    assert np.array_equal(g_obj, c_obj) and np.array_equal(bits(g_t), bits(c_t))
+    ts = (c_t * 0.999).astype(np.float32)
+    assert np.array_equal(d.trace_rays(O, Dr, ts, any_hit=True)[0], orc.is_occluded(O, Dr, ts))
+    for spp in (1, 5):
+        d.reset()
+        d.render(api.PATHTRACING, 0, spp, 1)
+        ref = orc.sample(W, H, cam, seeds, 0, spp)
+        assert rmse(d.accumulator()[..., :3], ref[..., :3]) <= 1e-5 * spp
+    d.render(api.RAYTRACING, 0, 1, 1, 5, 0)
+    assert rmse(d.accumulator()[..., :3], orc.trace(W, H, cam, api.RAYTRACING, 5)[..., :3]) <= 1e-5
+    d.close()
+
+
+def test_obj_mesh_with_spheres(tmp_path):
+    """cow.obj through the OBJ path plus BVH spheres (sphere leaves + triangle leaves in one tree)"""
+    W, H = 128, 72
+    s = api.HostScene().make_room()
+    s.load_logo()
+    s.load_obj(os.path.join(api.ASSETS, "cow.obj"), api.Material(api.DIFFUSE, (0.2, 0.8, 0.3)), (0.0, -0.2, 1.2))
+    s.add_sphere((-1.2, -0.4, 1.5), 0.5, api.Material(api.GLASS, (1, 1, 1), 1.52, (8, 2, 1)))
+    s.add_sphere((1.2, -0.4, 1.5), 0.45, api.Material(api.MIRROR))
+    s.finalize(api.REFERENCE_SAH)
+    orc = Oracle(s.desc)
+    cam, seeds = api.default_camera(W, H), api.seed_table(W * H)
+    d = api.Device(W, H)
+    d.upload(s.desc)
+    d.set_seeds(seeds)
+    obj, t = d.trace_primary()
+    o_obj, o_t = orc.primary_hits(W, H, cam)
+    assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+    assert set(np.unique(obj)) >= {1, 2}  # both spheres visible
+    d.render(api.PATHTRACING, 0, 4, 1)
+    assert rmse(d.accumulator()[..., :3], orc.sample(W, H, cam, seeds, 0, 4)[..., :3]) <= 4e-5
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def full():
+    """BASELINE.json configs[2]: ~1M triangles at 1920x1080"""
+    W, H = 1920, 1080
+    scene = api.mesh_scene(1000000, api.BINNED_SAH)
+    d = api.Device(W, H)
+    d.upload(scene.desc)
+    seeds = api.seed_table(W * H)
+    d.set_seeds(seeds)
+    yield scene, d, seeds
+    d.close()
+
+
+def test_full_size_primary_hits_bit_exact(full):
+    scene, d, _ = full
+    obj, t = d.trace_primary()
+    orc = Oracle(scene.desc)
+    o_obj, o_t = orc.primary_hits(1920, 1080, api.default_camera(1920, 1080))
+    assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+
+
+def test_full_size_image_and_properties(full):
+    scene, d, seeds = full
+    W, H = 1920, 1080
+    d.reset()
+    d.render(api.PATHTRACING, 0, 1, 1)
+    one = d.accumulator()
+    ref = Oracle(scene.desc).sample(W, H, api.default_camera(W, H), seeds, 0, 1)
+    assert rmse(one[..., :3], ref[..., :3]) <= 1e-5  # bar 1e-3
+    # determinism: queue order changes from run to run, per-path results must not
+    d.reset()
+    d.render(api.PATHTRACING, 0, 1, 1)
+    assert np.array_equal(bits(d.accumulator()), bits(one))
+    # batching: 4 samples in one batch == 4 batches of one sample (accumulation is in sample order either way)
+    d.reset()
+    d.render(api.PATHTRACING, 0, 4, 1)
+    four = d.accumulator()
+    os.environ["RTMI_BATCH"] = "1"
+    try:
+        d.reset()
+        d.render(api.PATHTRACING, 0, 4, 1)
+    finally:
+        del os.environ["RTMI_BATCH"]
+    assert np.array_equal(bits(d.accumulator()), bits(four))
+    # sample split: even + odd samples on "two ranks" sum to the same image up to float summation order
+    d.reset()
+    d.render(api.PATHTRACING, 0, 2, 2)
+    even = d.accumulator()
+    d.reset()
+    d.render(api.PATHTRACING, 1, 2, 2)
+    odd = d.accumulator()
+    assert np.allclose(even + odd, four, rtol=2e-6, atol=1e-6)
+    # counters: every path is one primary sample, every sample at least one extend ray
+    d.reset_stats()
+    d.render(api.PATHTRACING, 4, 1, 1)
+    st = d.stats()
+    assert st["primary_samples"] == W * H and st["extend_rays"] >= W * H and st["extend_walkers"] <= st["extend_rays"]
+    assert st["shadow_walkers"] <= st["shadow_rays"]
+    # finalize: r,g,b = (uint)(255 * min(1, acc / f)) on every pixel (precomp.h:449-465)
+    px = d.finalize(5)
+    acc = d.accumulator()
+    want = (np.float32(255.0) * np.minimum(np.float32(1.0), acc[..., :3] / np.float32(5.0))).astype(np.uint32)
+    assert np.array_equal(px, (want[..., 0] << 16) + (want[..., 1] << 8) + want[..., 2])
+
+
+def test_postfx_full_hd_matches_oracle():
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 1 << 24, (1080, 1920), dtype=np.uint32)
+    d = api.Device(1920, 1080)
+    fx = api.PostFx(1, 1, 1, 2.2, 5.0, 0.8)
+    out = d.postprocess(px, fx)
+    o = Oracle()
+    want = o.postfx(o.postfx(o.postfx(px, 0, 2.2), 1, 5.0), 2, 0.8)
+    mism = np.argwhere(out != want)
+    assert all(tuple(m) == (540, 960) for m in mism)  # centre pixel: 0/0 in the reference
+    d.close()
+
+
+def test_edge_cases_and_status_codes(default_scene):
+    L = api.device_lib()
+    d = api.Device(64, 36)
+    assert L.rtmi_render(d.h, api.PATHTRACING, 0, 1, 1, 5, 0) == -3  # RTMI_ERR_NO_SCENE
+    obj = np.zeros(64 * 36, np.int32)
+    assert L.rtmi_trace_primary(d.h, obj.ctypes.data, obj.ctypes.data) == -3
+    # analytic-only scene: no BVH primitives at all
+    room = api.HostScene().make_room().finalize()
+    d.upload(room.desc)
+    d.set_seeds(api.seed_table(64 * 36))
+    orc = Oracle(room.desc)
+    cam = api.default_camera(64, 36)
+    o, t = d.trace_primary()
+    oo, ot = orc.primary_hits(64, 36, cam)
+    assert np.array_equal(o, oo) and np.array_equal(bits(t), bits(ot)) and (o >= 0).all()
+    d.render(api.PATHTRACING, 0, 3, 1)
+    assert rmse(d.accumulator(), orc.sample(64, 36, cam, api.seed_table(64 * 36), 0, 3)) <= 3e-5
+    # empty scene: every ray misses, the image is black
+    empty = api.HostScene().finalize()
+    d.upload(empty.desc)
+    d.reset()
+    d.render(api.PATHTRACING, 0, 2, 1)
+    assert not d.accumulator().any() and (d.trace_primary()[0] == -1).all()
+    # argument checks
+    d.upload(default_scene.desc)
+    assert L.rtmi_render(d.h, api.PATHTRACING, 0, 0, 1, 5, 0) == -1
+    assert L.rtmi_render(d.h, api.PATHTRACING, 0, 1, 0, 5, 0) == -1
+    assert L.rtmi_render(d.h, 7, 0, 1, 1, 5, 0) == -1
+    assert L.rtmi_render(d.h, api.RAYTRACING, 0, 1, 1, 0, 0) == -1
+    assert b"max_depth" in L.rtmi_last_error(d.h)
+    # malformed node arrays are refused before any kernel sees them: RTMI_ERR_BVH
+    desc = default_scene.desc
+    good = desc.arrays()["nodes"].copy()
+    for mutate in ("cycle", "range", "bigleaf"):
+        bad = good.copy().view(np.int32)
+        if mutate == "cycle":
+            k = int(np.nonzero(bad[3:, 7] == 0)[0][5]) + 3
+            bad[k, 6] = 3  # an interior node pointing back at the first pair
+        elif mutate == "range":
+            bad[2, 6] = desc.n_nodes + 1
+        else:
+            k = int(np.nonzero(bad[3:, 7] > 0)[0][0]) + 3
+            bad[k, 7] = 1 << 20
+        d2 = api.SceneDesc.from_buffer_copy(desc)
+        d2.nodes = C.cast(bad.ctypes.data, C.POINTER(api.BvhNode))
+        assert L.rtmi_upload_scene(d.h, C.byref(d2)) == -4, mutate
+    # the scene uploaded before the failed uploads is still in place
+    o, t = d.trace_primary()
+    assert (o >= 0).any()
+    d.close()
+
+
+def test_renderer_surface(gold_small):
+    """Renderer::Init()/Tick(): default mode is Whitted (renderer.h:38); path tracing accumulates one sample per Tick
+    and finalises with f = accumulatedFrames; switching mode resets the accumulation (renderer.h:43-58)."""
+    r = api.Renderer(320, 180, 0)
+    assert r.L.rth_scene_make_default(r.scene.h, api.ASSETS.encode(), api.REFERENCE_SAH) == 0
+    r.init()
+    r.tick()
+    o = Oracle()
+    # includes the pixels whose Whitted value is slightly negative: the (uint) cast wraps as on x86-64 (k_finalize)
+    assert np.array_equal(r.pixels(), o.finalize(gold_small["whitted"], 0).reshape(180, 320))
+    r.set_mode(api.PATHTRACING)
+    for _ in range(4):
+        r.tick()
+    assert r.frames == 4
+    assert rmse(r.accumulator()[..., :3], gold_small["pt_4spp"][..., :3]) <= 4e-5
+    px = r.pixels()
+    ref = o.finalize(gold_small["pt_4spp"], 4).reshape(180, 320)
+    assert (px != ref).mean() < 1e-3
+    r.set_mode(api.PATHTRACING)  # reset
+    r.tick()
+    assert r.frames == 1 and rmse(r.accumulator()[..., :3], gold_small["pt_1spp"][..., :3]) <= 1e-5
+    r.set_mode(api.NORMAL)
+    r.tick()
+    assert rmse(r.accumulator()[..., :3], gold_small["view_normal"][..., :3]) <= 1e-5
+    r.set_postfx(api.PostFx(1, 0, 1, 2.2, 0.0, 0.8))
+    r.tick()
+    want = o.postfx(o.postfx(o.finalize(gold_small["view_normal"], 0).reshape(180, 320), 0, 2.2), 2, 0.8)
+    assert (r.pixels() != want).mean() < 1e-3

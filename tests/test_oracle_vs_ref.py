@@ -1,0 +1,59 @@
+"""Dev container only: the CPU oracle against the REFERENCE ITSELF (oracle/_ref, the reference's own sources compiled
+where they lie) on inputs the committed golden vectors do not contain -- other seeds, other sample indices, other
+rays.  Skipped where /root/reference or oracle/_ref is absent (the GPU box); there tests/test_oracle_golden.py pins
+the oracle against the fixtures this same build produced."""
+import numpy as np
+import pytest
+
+from raytracer_amd import api
+from oracle import ref as R
+from oracle.oracle import Oracle
+from conftest import bits
+
+pytestmark = pytest.mark.skipif(not R.available(320, 180), reason="reference tree / oracle/_ref not present")
+
+
+def same(a, b):
+    return np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+@pytest.fixture(scope="module")
+def pair(default_scene):
+    return R.Ref(320, 180), Oracle(default_scene.desc)
+
+
+def test_fresh_incoherent_rays(pair):
+    ref, orc = pair
+    rng = np.random.default_rng(7)
+    n = 20000
+    O = np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1).astype(np.float32)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    D[:200, 0] = 0  # zero direction components: the scalar slab test's NaN behaviour
+    D[200:400, 1] = 0
+    tmax = np.full(n, 1e34, np.float32)
+    r_obj, r_t = ref.find_nearest(O, D, tmax, qbvh=False)
+    for mode in (0, 1):
+        o_obj, o_t = orc.find_nearest(O, D, tmax, mode)
+        assert np.array_equal(o_obj, r_obj) and same(o_t, r_t)
+    ts = (r_t * rng.uniform(0.2, 1.5, n)).astype(np.float32)
+    assert np.array_equal(orc.is_occluded(O, D, ts), ref.is_occluded(O, D, ts, qbvh=False))
+    hit = r_obj >= 0
+    I = (O + r_t[:, None] * D)[hit].astype(np.float32)
+    assert all(same(a, b) for a, b in zip(orc.hit_attribs(r_obj[hit], I, D[hit]), ref.hit_attribs(r_obj[hit], I, D[hit])))
+
+
+def test_fresh_samples_and_seeds(pair):
+    ref, orc = pair
+    cam = api.default_camera(320, 180)
+    rng = np.random.default_rng(11)
+    seeds = rng.integers(1, 2 ** 32, 320 * 180, dtype=np.uint64).astype(np.uint32)
+    assert same(orc.sample(320, 180, cam, seeds, 37, 2), ref.sample(seeds, 37, 2, qbvh=False))
+    assert same(orc.sample(320, 180, cam, seeds, 3, 3, 5), ref.sample_strided(seeds, 3, 3, 5, qbvh=False))
+
+
+def test_trace_depths(pair):
+    ref, orc = pair
+    cam = api.default_camera(320, 180)
+    for depth in (1, 3, 8):
+        assert same(orc.trace(320, 180, cam, api.RAYTRACING, depth), ref.trace(api.RAYTRACING, depth, qbvh=False)), depth
