@@ -16,11 +16,12 @@ value = (closest-hit + any-hit rays traversed by all ranks, from device counters
 the K steps + reduce + finalize), in Mrays/s.  The reference's own "Mrays/s" (primary samples/s, renderer.cpp:639)
 is reported beside it as mpaths_per_s.
 
-roofline: the dominant kernel is k_extend (closest-hit BVH traversal).  achieved = algorithmic bytes of all
-k_extend launches of the timed region / their summed duration measured with hipEvents recorded on the stream the
-kernels run on (inside librtmi, rtmi_set_profiling), i.e. bytes per launch / mean launch duration.  Algorithmic bytes
-per extend ray = 64 B x node-pair records fetched + 48 B x leaf primitive records tested + 44 B of ray state
-(SURVEY 8d); the per-ray record counts come from a counting pass of the same kernels over the first step's samples.
+roofline: the dominant kernel is k_trace<closest> (closest-hit BVH walk of the rays that entered the root box).
+achieved = algorithmic bytes of all its launches in the timed region / their summed duration measured with hipEvents
+recorded on the stream the kernels run on (inside librtmi, rtmi_set_profiling), i.e. bytes per launch / mean launch
+duration.  Algorithmic bytes per walked ray = 64 B x node-pair records fetched + 48 B x leaf primitive records tested
++ 44 B of ray state (32 B read, 4 B walk index, 8 B hit write); the per-walker record counts
+come from a counting pass of the same kernels over the first step's samples.
 
 cpu_baseline: the CPU restatement (oracle/, kind "port"; validated bit-exact against the compiled reference) timed
 on this box's host cores over a bounded row subset of one sample of the same workload.  N=1, rank 0 only.
@@ -105,10 +106,10 @@ def main():
     step(0)
     dev.sync()
     cs = dev.stats()
-    pairs_per_ray = cs["extend_pairs"] / max(1, cs["extend_rays"])
-    prims_per_ray = cs["extend_prims"] / max(1, cs["extend_rays"])
-    spairs_per_ray = cs["shadow_pairs"] / max(1, cs["shadow_rays"])
-    sprims_per_ray = cs["shadow_prims"] / max(1, cs["shadow_rays"])
+    pairs_per_ray = cs["extend_pairs"] / max(1, cs["extend_walkers"])
+    prims_per_ray = cs["extend_prims"] / max(1, cs["extend_walkers"])
+    spairs_per_ray = cs["shadow_pairs"] / max(1, cs["shadow_walkers"])
+    sprims_per_ray = cs["shadow_prims"] / max(1, cs["shadow_walkers"])
     dev.set_profiling(False, False)
 
     for i in range(a.warmup):
@@ -138,8 +139,8 @@ def main():
     total_rays, ext_rays, sh_rays, paths = [float(x) for x in rays.tolist()]
 
     if rank == 0:
-        bytes_per_extend_ray = 64.0 * pairs_per_ray + 48.0 * prims_per_ray + 44.0
-        ext_bytes = st["extend_rays"] * bytes_per_extend_ray
+        bytes_per_extend_ray = 64.0 * pairs_per_ray + 48.0 * prims_per_ray + 44.0  # per ray that walks the BVH
+        ext_bytes = st["extend_walkers"] * bytes_per_extend_ray
         ext_s = st["ms_extend"] * 1e-3
         n_launch = max(1, st["n_extend_launches"])
         achieved = ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
@@ -155,10 +156,11 @@ def main():
             "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays,
             "extend_walkers": float(st["extend_walkers"]), "shadow_walkers": float(st["shadow_walkers"]), "rays_per_path": total_rays / max(1.0, paths),
             "scene_build_s": build_s,
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": a.traffic_bytes_per_launch, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
-                         "launches": st["n_extend_launches"], "bytes_per_ray": bytes_per_extend_ray, "node_pairs_per_ray": pairs_per_ray,
-                         "leaf_prims_per_ray": prims_per_ray, "shadow_node_pairs_per_ray": spairs_per_ray, "shadow_leaf_prims_per_ray": sprims_per_ray},
+                         "launches": st["n_extend_launches"], "bytes_per_walked_ray": bytes_per_extend_ray, "node_pairs_per_walked_ray": pairs_per_ray,
+                         "leaf_prims_per_walked_ray": prims_per_ray, "shadow_node_pairs_per_walked_ray": spairs_per_ray,
+                         "shadow_leaf_prims_per_walked_ray": sprims_per_ray},
             "kernel_ms": {"extend": st["ms_extend"], "shade": st["ms_shade"], "connect": st["ms_connect"], "other": st["ms_other"]},
         }
         if world == 1 and not a.no_cpu_baseline:
