@@ -160,7 +160,7 @@ def main():
                          "traffic": a.traffic_bytes_per_launch, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
                          "launches": st["n_extend_launches"], "bytes_per_walked_ray": bytes_per_extend_ray, "node_pairs_per_walked_ray": pairs_per_ray,
                          "leaf_prims_per_walked_ray": prims_per_ray, "shadow_node_pairs_per_walked_ray": spairs_per_ray,
-                         "shadow_leaf_prims_per_walked_ray": sprims_per_ray},
+                         "shadow_leaf_prims_per_walked_ray": sprims_per_ray, "longest_walk_steps": [cs["max_extend_steps"], cs["max_shadow_steps"]]},
             "kernel_ms": {"extend": st["ms_extend"], "shade": st["ms_shade"], "connect": st["ms_connect"], "other": st["ms_other"]},
         }
         if world == 1 and not a.no_cpu_baseline:

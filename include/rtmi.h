@@ -98,6 +98,8 @@ typedef struct rtmi_stats {
 	uint64_t n_extend_launches, n_shade_launches, n_connect_launches;
 	uint64_t extend_walkers;    /* closest-hit rays that passed the root box test and walked the BVH (the rest end in the analytic tests) */
 	uint64_t shadow_walkers;    /* same for any-hit rays */
+	uint64_t suspended;         /* walks parked at the end of a launch and resumed in the next bounce (tail control) */
+	uint64_t max_extend_steps, max_shadow_steps; /* longest single walk in steps (pairs + leaf records); count_nodes only */
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,

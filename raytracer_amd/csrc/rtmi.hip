@@ -38,7 +38,7 @@ struct PathState
 	float4* o_t;    // ray origin, hit distance
 	float4* d_h;    // ray direction, hit object index (int bits)
 	float4* T_s;    // throughput, rng state (uint bits)
-	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel) | flags << 30
+	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel) | META_SUSPENDED | flags << 30
 };
 struct ShadowQueue // only the shadow rays that have to walk the BVH
 {
@@ -48,20 +48,27 @@ struct ShadowQueue // only the shadow rays that have to walk the BVH
 };
 struct CamProp { float4 pos, tl, tr, bl; };
 
-struct DevCounters // the first 32 bytes are zeroed per render batch
+struct DevCounters // the first 64 bytes are zeroed per render batch
 {
 	uint32_t n_state[2];   // ping-pong path queue lengths
 	uint32_t n_walk[2];    // rays of that queue that enter the BVH root box (indices in wq[])
-	uint32_t n_shadow;     // shadow queue length of the current bounce
+	uint32_t n_shadow[2];  // ping-pong shadow queue lengths
+	uint32_t n_rec[2];     // suspend records written by k_trace<closest> of that bounce parity
+	uint32_t pad0[2];
 	uint32_t pool_extend;  // next unclaimed entry of the running k_trace<closest> launch (persistent waves pull chunks from it)
 	uint32_t pool_connect; // same for k_trace<any>
-	uint32_t pad;
-	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers;
+	uint32_t pending;      // paths the next bounce starts with (host loop termination)
+	uint32_t pad[3];
+	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
+	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
 };
 
 #define FLAG_SPECULAR 1u
 #define FLAG_INSIDE 2u
-#define META_SLOT_MASK 0x3FFFFFFFu
+#define META_SLOT_MASK 0x1FFFFFFFu
+#define META_SUSPENDED 0x20000000u // the closest-hit walk of this path was parked (k_trace); k_shade passes it through
+#define RESUME_BIT 0x80000000u     // walk queue entry / shadow slot field: resume from a suspend record
+#define REC_HEADER 6               // suspend record: cur, sp, k, h.obj, h.pos, -, then the stack
 
 // ---- queue append.  One device-scope atomic on a single word retires at ~88 per microsecond on this chip, so a
 // per-wave atomic (half a million waves per bounce) is the bottleneck of a wavefront path tracer; here a whole
@@ -172,30 +179,56 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 //                by the creating kernel is the starting t.
 //   ANY = true:  any hit (IntersectBVHShadowRay, bvh.h:640-688) over the shadow queue; E[slot] += contribution when
 //                nothing is hit (renderer.cpp:339-344).
+// Tail control: a launch lasts as long as its longest ray, and a few rays of this scene walk > 1500 steps against a
+// mean of 90, so from the third bounce on most of a launch was one wave finishing one ray.  Once a wave has no new
+// rays to fetch, a CLOSEST-HIT ray that is still walking `budget` steps later is SUSPENDED: its traversal state (node,
+// leaf progress, stack, best hit) goes to a record in HBM and the ray resumes in the next bounce's launch of this
+// kernel, next to that bounce's new rays; its path simply lags one bounce.  Per-path arithmetic and event order are
+// unchanged, so results do not depend on which rays were parked.  Shadow rays are never parked: a lagging
+// contribution would meet the path's next shadow ray in one launch (two read-modify-writes of E[slot]).
+struct TraceArgs
+{
+	PathState st;            // closest: the rays' state set
+	ShadowQueue sq;          // any: this bounce's shadow queue
+	float4* E;
+	const uint32_t* wq;      // closest: walk queue (entry | RESUME_BIT)
+	const uint32_t* count_ptr;
+	const uint32_t* rays_ptr;
+	uint32_t* pool;
+	const uint32_t* rec_in;  // records written by the previous bounce
+	uint32_t* rec_out;       // records written by this launch
+	uint32_t* n_rec_out;
+	const uint32_t* n_rec_in;
+	uint32_t rec_cap;
+	int rec_stride, refill, budget; // budget 0: never suspend
+};
+
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ wq,
-	const uint32_t* __restrict__ count_ptr, const uint32_t* __restrict__ rays_ptr, DevCounters* ctr, uint32_t* pool, int refill )
+__global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	uint32_t* stack = lds_stack + threadIdx.x;
-	const uint32_t n = *count_ptr;
+	const uint32_t n = *a.count_ptr;
 	const int lane = threadIdx.x & 63;
+	const int refill = a.refill;
 	// chunk: large enough that the pool counter is not the bottleneck, small enough that the last chunks balance
 	const uint32_t waves = gridDim.x * ( BLOCK / 64 );
 	uint32_t chunk = n / ( waves * 4u );
 	chunk = chunk < 64u ? 64u : ( chunk > 512u ? 512u : chunk );
 	uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
 	// lane state: !has = empty; has && cur == RT_DONE = finished, waiting to be retired; else walking
-	bool has = false, exhausted = false, inexact = false, occluded = false;
+	bool has = false, exhausted = false, inexact = false, occluded = false, resumed = false;
 	uint32_t cur = RT_DONE, entry = 0, slot = 0;
 	int sp = 0, k = 0; // stack pointer; primitives of the current leaf already tested
+	int tail_steps = 0; // steps since this wave ran out of new rays
 	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), rD = mk3( 0, 0, 1 );
 	RayHit h; h.t = 0, h.obj = -1, h.pos = -1;
 	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	uint32_t steps = 0, maxSteps = 0, nSusp = 0; // COUNT only (nSusp always)
 	for (;;)
 	{
 		const unsigned long long walking = __ballot( has && cur != RT_DONE );
-		if (walking == 0 || 64 - __popcll( walking ) >= refill)
+		if (walking == 0 || 64 - __popcll( walking ) >= refill || ( !ANY && exhausted && a.budget > 0 && tail_steps >= a.budget ))
 		{
 			// retire finished rays
 			if (has && cur == RT_DONE)
@@ -204,18 +237,19 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 				{
 					if (!occluded)
 					{
-						const float4 c = sq.c[entry];
-						float4 e = E[slot];
+						const float4 c = a.sq.c[entry];
+						float4 e = a.E[slot];
 						e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
-						E[slot] = e;
+						a.E[slot] = e;
 					}
 				}
-				else if (h.pos >= 0) // a BVH primitive beat the analytic hit
+				else if (h.pos >= 0 || resumed) // a BVH primitive beat the analytic hit (a resumed ray's fields held its record)
 				{
-					st.o_t[entry].w = h.t;
-					st.d_h[entry].w = __int_as_float( h.obj );
+					a.st.o_t[entry].w = h.t;
+					a.st.d_h[entry].w = __int_as_float( h.obj );
 				}
 				has = false, inexact = false;
+				if (COUNT) maxSteps = steps > maxSteps ? steps : maxSteps, steps = 0;
 			}
 			// hand the free lanes new rays
 			if (!exhausted)
@@ -225,7 +259,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 				if (chunk_next == chunk_end)
 				{
 					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd( pool, chunk );
+					if (lane == 0) base = atomicAdd( a.pool, chunk );
 					base = __shfl( base, 0, 64 );
 					if (base >= n) exhausted = true, chunk_next = chunk_end = 0;
 					else chunk_next = base, chunk_end = ( n - base < chunk ) ? n : base + chunk;
@@ -235,25 +269,61 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 					const uint32_t my = chunk_next + __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0 ) );
 					if (!has && my < chunk_end)
 					{
-						has = true, sp = 0, k = 0, occluded = false, h.pos = -1;
+						has = true, sp = 0, k = 0, occluded = false, h.pos = -1, cur = s.root_ref; // the root box test passed in the creating kernel
+						uint32_t rec = 0;
 						if (ANY)
 						{
 							entry = my;
-							const float4 ot = sq.o_t[entry], ds = sq.d_s[entry];
+							const float4 ot = a.sq.o_t[entry], ds = a.sq.d_s[entry];
 							O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
 						}
 						else
 						{
-							entry = wq[my];
-							const float4 ot = st.o_t[entry], dh = st.d_h[entry];
+							const uint32_t e = a.wq[my];
+							entry = e & ~RESUME_BIT, resumed = ( e & RESUME_BIT ) != 0;
+							const float4 ot = a.st.o_t[entry], dh = a.st.d_h[entry];
 							O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far
+							if (resumed) rec = __float_as_uint( dh.w ), a.st.meta[entry] &= ~META_SUSPENDED;
+						}
+						if (!ANY && resumed)
+						{
+							const uint32_t* r = a.rec_in + (size_t)rec * a.rec_stride;
+							cur = r[0], sp = (int)r[1], k = (int)r[2], h.obj = (int)r[3], h.pos = (int)r[4];
+							for (int i = 0; i < sp; i++) stack[i * BLOCK] = r[REC_HEADER + i];
 						}
 						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 						inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						cur = s.root_ref; // the root box test passed in the creating kernel
 					}
 					chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
 					if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
+				}
+				if (exhausted) tail_steps = 0;
+			}
+			else if (!ANY && a.budget > 0 && tail_steps >= a.budget)
+			{
+				// park the rays that are still walking
+				const bool want = has && cur != RT_DONE;
+				const unsigned long long m = __ballot( want );
+				if (m)
+				{
+					const int leader = __ffsll( (long long)m ) - 1;
+					const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) );
+					uint32_t base = 0;
+					if (lane == leader) base = atomicAdd( a.n_rec_out, (uint32_t)__popcll( m ) );
+					const uint32_t idx = __shfl( base, leader, 64 ) + rank;
+					const bool park = want && idx < a.rec_cap; // no room: keep walking for another budget
+					if (park)
+					{
+						uint32_t* r = a.rec_out + (size_t)idx * a.rec_stride;
+						r[0] = cur, r[1] = (uint32_t)sp, r[2] = (uint32_t)k, r[3] = (uint32_t)h.obj, r[4] = (uint32_t)h.pos;
+						for (int i = 0; i < sp; i++) r[REC_HEADER + i] = stack[i * BLOCK];
+						a.st.o_t[entry].w = h.t;
+						a.st.d_h[entry].w = __uint_as_float( idx );
+						a.st.meta[entry] |= META_SUSPENDED;
+						has = false, inexact = false, nSusp++;
+						if (COUNT) maxSteps = steps > maxSteps ? steps : maxSteps, steps = 0;
+					}
+					tail_steps = 0;
 				}
 			}
 			if (__ballot( has ) == 0)
@@ -262,6 +332,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 				continue;
 			}
 		}
+		tail_steps++;
 		// one step per iteration for the majority kind: the lanes at an interior node test its two children, or the
 		// lanes in a leaf test one primitive.  The minority waits; it becomes the majority as the others arrive.
 		const bool atNode = has && !( cur & RT_LEAF ), atLeaf = has && ( cur & RT_LEAF ) && cur != RT_DONE;
@@ -269,14 +340,14 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 		{
 			if (__ballot( has && inexact ) != 0)
 			{
-				if (atNode) { if (COUNT) tc.pairs++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+				if (atNode) { if (COUNT) tc.pairs++, steps++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
 			}
-			else if (atNode) { if (COUNT) tc.pairs++; cur = interior_step<ANY, false>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+			else if (atNode) { if (COUNT) tc.pairs++, steps++; cur = interior_step<ANY, false>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
 		}
 		else if (atLeaf)
 		{
 			const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
-			if (COUNT) tc.prims++;
+			if (COUNT) tc.prims++, steps++;
 			const bool hit = isect_prim<ANY>( s, first + k, O, D, h );
 			k++;
 			if (ANY && hit) occluded = true, cur = RT_DONE, k = 0;
@@ -287,12 +358,17 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, PathState st, Shad
 	{
 		wave_add64( tc.pairs, ANY ? &ctr->shadow_pairs : &ctr->extend_pairs );
 		wave_add64( tc.prims, ANY ? &ctr->shadow_prims : &ctr->extend_prims );
+		for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_down( maxSteps, o, 64 ); maxSteps = v > maxSteps ? v : maxSteps; }
+		if (lane == 0 && maxSteps) atomicMax( &ctr->max_steps[ANY ? 1 : 0], maxSteps );
 	}
-	// every closest-hit ray of the bounce counts as an extend ray, whether it had to walk the BVH or not
+	if (__ballot( nSusp != 0 )) wave_add64( nSusp, &ctr->suspended );
+	// every closest-hit ray of the bounce counts as an extend ray, whether it had to walk the BVH or not; a resumed
+	// ray is not a new ray
 	if (threadIdx.x == 0 && blockIdx.x == 0)
 	{
-		if (!ANY) atomicAdd( &ctr->extend_rays, (unsigned long long)*rays_ptr );
-		atomicAdd( ANY ? &ctr->shadow_walkers : &ctr->extend_walkers, (unsigned long long)n );
+		const uint32_t nres = ANY ? 0u : ( *a.n_rec_in < a.rec_cap ? *a.n_rec_in : a.rec_cap ); // resumed rays in this launch
+		if (!ANY) atomicAdd( &ctr->extend_rays, (unsigned long long)( *a.rays_ptr - nres ) );
+		atomicAdd( ANY ? &ctr->shadow_walkers : &ctr->extend_walkers, (unsigned long long)( n - nres ) );
 	}
 }
 
@@ -308,7 +384,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 	__syncthreads();
 	const uint32_t i = blockIdx.x * SBLOCK + threadIdx.x;
 	const uint32_t n = *n_in;
-	bool push_next = false, walk_next = false, shadow_any = false, push_shadow = false;
+	bool push_next = false, walk_next = false, shadow_any = false, push_shadow = false, parked = false;
 	uint32_t slot = 0, flags = 0, rng = 0;
 	f3 newO, newD, shO, shD, contrib, T;
 	float shT = 0;
@@ -317,12 +393,18 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 	{
 		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
 		const uint32_t meta = in.meta[i];
-		slot = meta & META_SLOT_MASK, flags = meta >> 30;
+		slot = meta & META_SLOT_MASK, flags = meta >> 30, parked = ( meta & META_SUSPENDED ) != 0;
 		const f3 O = mk3( ot ), D = mk3( dh );
 		const float t = ot.w;
 		const int obj = __float_as_int( dh.w );
 		T = mk3( ts ), rng = __float_as_uint( ts.w );
-		if (obj != -1)
+		if (parked)
+		{
+			// the closest-hit walk of this path is not finished (k_trace parked it): hand the entry on unchanged; t holds
+			// the best distance so far and the object field the index of its suspend record
+			newO = O, newD = D, nh.t = t, nh.obj = obj, push_next = true, walk_next = true;
+		}
+		else if (obj != -1)
 		{
 			const f3 I = O + t * D;
 			HitAttr a;
@@ -425,7 +507,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 			}
 		}
 		// the rays created here start their life here: everything of FindNearest / IsOccluded before the BVH walk
-		if (push_next) walk_next = begin_closest( s, newO, newD, nh );
+		if (push_next && !parked) walk_next = begin_closest( s, newO, newD, nh );
 		if (shadow_any)
 		{
 			bool occluded;
@@ -452,8 +534,8 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 		out.o_t[j] = make_float4( newO.x, newO.y, newO.z, nh.t );
 		out.d_h[j] = make_float4( newD.x, newD.y, newD.z, __int_as_float( nh.obj ) );
 		out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
-		out.meta[j] = slot | ( flags << 30 );
-		if (walk_next) wq_out[idx[1]] = j;
+		out.meta[j] = slot | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u );
+		if (walk_next) wq_out[idx[1]] = j | ( parked ? RESUME_BIT : 0u );
 	}
 	if (push_shadow)
 	{
@@ -466,7 +548,12 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 }
 
 // end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
-__global__ void k_next_bounce( DevCounters* ctr, int consumed ) { ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow = 0, ctr->pool_extend = 0, ctr->pool_connect = 0; }
+__global__ void k_next_bounce( DevCounters* ctr, int consumed )
+{
+	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_extend = 0, ctr->pool_connect = 0;
+	ctr->n_rec[consumed ^ 1] = 0; // read by this bounce's walk, written again by the next bounce's
+	ctr->pending = ctr->n_state[consumed ^ 1];
+}
 
 // ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
 __global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E, int WH, int S )
@@ -751,7 +838,11 @@ struct rtmi_ctx
 	// path tracing state, sized for `batch` samples in flight
 	int batch = 0;
 	PathState st[2] = {};       // queue-ordered path state, ping-pong
-	ShadowQueue sq = {};
+	ShadowQueue sq[2] = {};     // ping-pong
+	uint32_t* rec[2] = { 0, 0 }; // suspend records of k_trace<closest>, ping-pong
+	uint32_t rec_cap = 0;
+	int rec_stride = 0;
+	int budget = 128;           // tail steps after which a still-walking ray is parked (0 = never)
 	float4* E = 0;              // radiance estimate per slot (sample_in_batch * W*H + pixel)
 	uint32_t* wq[2] = { 0, 0 }; // per state set: entries that walk the BVH
 	DevCounters* ctr = 0;
@@ -832,23 +923,28 @@ static void free_scene( rtmi_ctx* c )
 static void free_batch( rtmi_ctx* c )
 {
 	void* ps[] = { c->st[0].o_t, c->st[0].d_h, c->st[0].T_s, c->st[0].meta, c->st[1].o_t, c->st[1].d_h, c->st[1].T_s, c->st[1].meta,
-		c->sq.o_t, c->sq.d_s, c->sq.c, c->E, c->wq[0], c->wq[1] };
+		c->sq[0].o_t, c->sq[0].d_s, c->sq[0].c, c->sq[1].o_t, c->sq[1].d_s, c->sq[1].c, c->E, c->wq[0], c->wq[1], c->rec[0], c->rec[1] };
 	for (void* p : ps) if (p) (void)hipFree( p );
-	c->st[0] = c->st[1] = PathState{}, c->sq = ShadowQueue{}, c->E = 0, c->wq[0] = c->wq[1] = 0, c->batch = 0;
+	c->st[0] = c->st[1] = PathState{}, c->sq[0] = c->sq[1] = ShadowQueue{}, c->E = 0, c->wq[0] = c->wq[1] = 0, c->batch = 0;
+	c->rec[0] = c->rec[1] = 0, c->rec_cap = 0;
 }
-// 176 bytes of queue state per path in flight: 2 x 52 B path state, 16 B E, 48 B shadow ray, 2 x 4 B walk index
+// Queue state per path in flight: 2 x 52 B path state, 16 B E, 2 x 48 B shadow ray, 2 x 4 B walk index = 224 B, plus suspend
+// records for one path in eight (2 x (6 + stack depth) words each).
 static int ensure_batch( rtmi_ctx* c, int S )
 {
 	if (c->batch >= S) return RTMI_OK;
 	free_batch( c );
 	const size_t n = (size_t)S * c->W * c->H;
+	const size_t cap = n / 8 + 1024;
+	c->rec_stride = c->stack_depth + REC_HEADER;
 	int r = RTMI_OK;
 	for (int k = 0; k < 2 && !r; k++)
 		( r = dev_alloc( c, &c->st[k].o_t, n ) ) || ( r = dev_alloc( c, &c->st[k].d_h, n ) ) || ( r = dev_alloc( c, &c->st[k].T_s, n ) ) || ( r = dev_alloc( c, &c->st[k].meta, n ) ) ||
-			( r = dev_alloc( c, &c->wq[k], n ) );
-	if (!r) ( r = dev_alloc( c, &c->sq.o_t, n ) ) || ( r = dev_alloc( c, &c->sq.d_s, n ) ) || ( r = dev_alloc( c, &c->sq.c, n ) ) || ( r = dev_alloc( c, &c->E, n ) );
+			( r = dev_alloc( c, &c->wq[k], n ) ) || ( r = dev_alloc( c, &c->sq[k].o_t, n ) ) || ( r = dev_alloc( c, &c->sq[k].d_s, n ) ) || ( r = dev_alloc( c, &c->sq[k].c, n ) ) ||
+			( r = dev_alloc( c, &c->rec[k], cap * c->rec_stride ) );
+	if (!r) r = dev_alloc( c, &c->E, n );
 	if (r) { free_batch( c ); return r; }
-	c->batch = S;
+	c->batch = S, c->rec_cap = (uint32_t)cap;
 	return RTMI_OK;
 }
 
@@ -873,7 +969,9 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties( &prop, device_id ) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-		const char* e = getenv( "RTMI_REFILL" );
+		const char* e = getenv( "RTMI_STEP_BUDGET" );
+		if (e && atoi( e ) >= 0) c->budget = atoi( e );
+		e = getenv( "RTMI_REFILL" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= 64) c->refill = atoi( e );
 	}
 	const size_t n = (size_t)width * height;
@@ -1086,6 +1184,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	ds.wl_intensity = d->whitted_intensity;
 
 	free_scene( c );
+	free_batch( c ); // the suspend records are sized by the stack depth
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
 	{
@@ -1134,23 +1233,27 @@ static inline int nsblocks( size_t n ) { return (int)( ( n + SBLOCK - 1 ) / SBLO
 // persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need
 static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); }
 
-static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper )
+static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper, int budget )
 {
 	const size_t lds = stack_bytes( c );
 	hipStream_t s = c->stream;
 	DevCounters* ctr = c->ctr;
-	const uint32_t* count = any ? &ctr->n_shadow : &ctr->n_walk[set];
-	uint32_t* pool = any ? &ctr->pool_connect : &ctr->pool_extend;
+	TraceArgs a = {};
+	a.st = c->st[set], a.sq = c->sq[set], a.E = c->E, a.wq = c->wq[set];
+	a.count_ptr = any ? &ctr->n_shadow[set] : &ctr->n_walk[set], a.rays_ptr = &ctr->n_state[set];
+	a.pool = any ? &ctr->pool_connect : &ctr->pool_extend;
+	a.rec_in = c->rec[set ^ 1], a.rec_out = c->rec[set], a.n_rec_out = &ctr->n_rec[set], a.n_rec_in = &ctr->n_rec[set ^ 1];
+	a.rec_cap = c->rec_cap, a.rec_stride = c->rec_stride, a.refill = c->refill, a.budget = budget;
 	ScopedTimer t( c, any ? 2 : 0 );
 	if (any)
 	{
-		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
-		else hipLaunchKernelGGL( ( k_trace<true, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
+		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		else hipLaunchKernelGGL( ( k_trace<true, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 	else
 	{
-		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<false, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
-		else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, c->st[set], c->sq, c->E, c->wq[set], count, &ctr->n_state[set], ctr, pool, c->refill );
+		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<false, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 }
 static void launch_primary( rtmi_ctx* c, uint32_t N, int sample_begin, int stride )
@@ -1167,24 +1270,25 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 	const uint32_t N = (uint32_t)( (size_t)S * WH );
 	hipStream_t s = c->stream;
 	DevCounters* ctr = c->ctr;
-	HIPCHK( hipMemsetAsync( ctr, 0, 32, s ) ); // queue lengths and pools
+	HIPCHK( hipMemsetAsync( ctr, 0, 64, s ) ); // queue lengths and pools
 	launch_primary( c, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
-	int cur = 0;        // state set holding the rays of this bounce
+	int cur = 0;        // state / shadow queue set of this bounce
 	for (int bounce = 0;; bounce++)
 	{
-		launch_trace( c, false, cur, upper );
+		launch_trace( c, false, cur, upper, c->budget );
 		{
 			ScopedTimer t( c, 1 );
-			hipLaunchKernelGGL( k_shade, dim3( nsblocks( upper ) ), dim3( SBLOCK ), 0, s, c->ds, c->st[cur], c->st[cur ^ 1], c->sq, c->E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
-				c->wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow, ctr );
+			hipLaunchKernelGGL( k_shade, dim3( nsblocks( upper ) ), dim3( SBLOCK ), 0, s, c->ds, c->st[cur], c->st[cur ^ 1], c->sq[cur], c->E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
+				c->wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
-		launch_trace( c, true, cur, upper ); // this bounce's shadow rays (at most `upper` of them)
+		launch_trace( c, true, cur, upper, c->budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
+		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
 		c->stats.bounce_launches++;
-		// read back the length of the queue that feeds bounce+1; it is looked at two iterations later
+		// read back what the next bounce starts with (paths + carried shadow rays); it is looked at two iterations later
 		const int slot = bounce & 3;
-		HIPCHK( hipMemcpyAsync( &c->host_counts[slot], &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost, s ) );
+		HIPCHK( hipMemcpyAsync( &c->host_counts[slot], &ctr->pending, 4, hipMemcpyDeviceToHost, s ) );
 		HIPCHK( hipEventRecord( c->count_ev[slot], s ) );
 		if (bounce >= 2)
 		{
@@ -1193,7 +1297,6 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 			upper = std::min( upper, c->host_counts[old] );
 		}
 		if (upper == 0) break;
-		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
 		cur ^= 1;
 	}
 	{
@@ -1212,7 +1315,8 @@ static int fetch_counters( rtmi_ctx* c )
 	c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
 	c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
 	c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
-	c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers;
+	c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
+	c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
 	HIPCHK( hipMemsetAsync( c->ctr, 0, sizeof( DevCounters ), c->stream ) );
 	return RTMI_OK;
 }
@@ -1269,9 +1373,9 @@ int rtmi_trace_primary( rtmi_ctx* c, int32_t* obj_out, float* t_out )
 	int* dobj = 0; float* dt = 0;
 	if (( r = dev_alloc( c, &dobj, WH ) )) return r;
 	if (( r = dev_alloc( c, &dt, WH ) )) { (void)hipFree( dobj ); return r; }
-	hipError_t e0 = hipMemsetAsync( c->ctr, 0, 32, c->stream );
+	hipError_t e0 = hipMemsetAsync( c->ctr, 0, 64, c->stream );
 	launch_primary( c, (uint32_t)WH, 0, 1 );
-	launch_trace( c, false, 0, (uint32_t)WH );
+	launch_trace( c, false, 0, (uint32_t)WH, 0 ); // no step budget: every ray finishes in this launch
 	hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, c->stream, c->st[0], WH, dobj, dt );
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
