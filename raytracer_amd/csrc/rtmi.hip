@@ -54,10 +54,10 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 	uint32_t n_walk[2];    // rays of that queue that enter the BVH root box (indices in wq[])
 	uint32_t n_shadow[2];  // ping-pong shadow queue lengths
 	uint32_t n_rec[2];     // suspend records written by k_trace<closest> of that bounce parity
-	uint32_t pad0[2];
+	uint32_t n_srec[2];    // same for k_trace<any>
 	uint32_t pool_extend;  // next unclaimed entry of the running k_trace<closest> launch (persistent waves pull chunks from it)
 	uint32_t pool_connect; // same for k_trace<any>
-	uint32_t pending;      // paths the next bounce starts with (host loop termination)
+	uint32_t pending;      // paths + carried shadow rays that the next bounce starts with (host loop termination)
 	uint32_t pad[3];
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
 	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
@@ -142,7 +142,7 @@ __device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tm
 }
 
 // ---- ray generation (bounce 0): camera ray, per-(pixel, sample) rng state, analytic part of FindNearest --------------
-__global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, float4* __restrict__ E, uint32_t N, CamProp cam, int W, int H, float invW, float invH,
+__global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, float4* __restrict__ E, float4* __restrict__ Es, uint32_t N, CamProp cam, int W, int H, float invW, float invH,
 	const uint32_t* __restrict__ seeds, int sample_begin, int sample_stride, uint32_t* __restrict__ wq, DevCounters* ctr )
 {
 	__shared__ uint32_t lds[16];
@@ -160,6 +160,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 		st.T_s[i] = make_float4( 1, 1, 1, __uint_as_float( sample_seed( seeds[p], sidx ) ) );
 		st.meta[i] = i | ( FLAG_SPECULAR << 30 );
 		E[i] = make_float4( 0, 0, 0, 0 );
+		Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 ); // 4 x int64 zero
 	}
 	const bool push[1] = { walk };
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
@@ -179,17 +180,39 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 //                by the creating kernel is the starting t.
 //   ANY = true:  any hit (IntersectBVHShadowRay, bvh.h:640-688) over the shadow queue; E[slot] += contribution when
 //                nothing is hit (renderer.cpp:339-344).
+// Contribution of a shadow ray that had to walk the BVH.  These arrive in an order that depends on scheduling (and, with
+// parked rays, a bounce late), so they are not added into the float chain E[slot] but summed EXACTLY: 64-bit fixed point,
+// 2^-40 units, integer atomics.  Integer addition is associative, so the sum does not depend on arrival order and no
+// read-modify-write of a float is shared between lanes; k_accumulate adds float(Es) to the path's E once.
+// (Range +-2^23; a contribution below 2^-40 ~ 1e-12 is dropped.  A non-finite one goes to E so that it stays visible.)
+#define ES_SCALE 1099511627776.0f // 2^40
+__device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* E, uint32_t slot, float4 c )
+{
+	const bool finite = fabsf( c.x ) < 4194304.0f && fabsf( c.y ) < 4194304.0f && fabsf( c.z ) < 4194304.0f; // false for NaN
+	if (finite)
+	{
+		unsigned long long* p = (unsigned long long*)( Es + 4 * (size_t)slot );
+		const long long x = (long long)( c.x * ES_SCALE ), y = (long long)( c.y * ES_SCALE ), z = (long long)( c.z * ES_SCALE );
+		if (x) atomicAdd( p, (unsigned long long)x );
+		if (y) atomicAdd( p + 1, (unsigned long long)y );
+		if (z) atomicAdd( p + 2, (unsigned long long)z );
+	}
+	else atomicAdd( &E[slot].x, c.x ), atomicAdd( &E[slot].y, c.y ), atomicAdd( &E[slot].z, c.z );
+}
+
 // Tail control: a launch lasts as long as its longest ray, and a few rays of this scene walk > 1500 steps against a
 // mean of 90, so from the third bounce on most of a launch was one wave finishing one ray.  Once a wave has no new
 // rays to fetch, a CLOSEST-HIT ray that is still walking `budget` steps later is SUSPENDED: its traversal state (node,
 // leaf progress, stack, best hit) goes to a record in HBM and the ray resumes in the next bounce's launch of this
 // kernel, next to that bounce's new rays; its path simply lags one bounce.  Per-path arithmetic and event order are
-// unchanged, so results do not depend on which rays were parked.  Shadow rays are never parked: a lagging
-// contribution would meet the path's next shadow ray in one launch (two read-modify-writes of E[slot]).
+// unchanged, so results do not depend on which rays were parked.  A parked SHADOW ray is carried into the next
+// bounce's shadow queue; its contribution then arrives late and may meet the same path's next shadow ray in one launch,
+// which is why the contributions of walked shadow rays are summed order-independently (Es, below).
 struct TraceArgs
 {
 	PathState st;            // closest: the rays' state set
-	ShadowQueue sq;          // any: this bounce's shadow queue
+	ShadowQueue sq, sq_out;  // any: this bounce's queue; the next bounce's queue (receives the parked shadow rays)
+	long long* Es;           // any: fixed-point sum of the contributions of walked shadow rays, 4 x int64 per slot
 	float4* E;
 	const uint32_t* wq;      // closest: walk queue (entry | RESUME_BIT)
 	const uint32_t* count_ptr;
@@ -199,6 +222,7 @@ struct TraceArgs
 	uint32_t* rec_out;       // records written by this launch
 	uint32_t* n_rec_out;
 	const uint32_t* n_rec_in;
+	uint32_t* n_shadow_out;
 	uint32_t rec_cap;
 	int rec_stride, refill, budget; // budget 0: never suspend
 };
@@ -228,20 +252,14 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	for (;;)
 	{
 		const unsigned long long walking = __ballot( has && cur != RT_DONE );
-		if (walking == 0 || 64 - __popcll( walking ) >= refill || ( !ANY && exhausted && a.budget > 0 && tail_steps >= a.budget ))
+		if (walking == 0 || 64 - __popcll( walking ) >= refill || ( exhausted && a.budget > 0 && tail_steps >= a.budget ))
 		{
 			// retire finished rays
 			if (has && cur == RT_DONE)
 			{
 				if (ANY)
 				{
-					if (!occluded)
-					{
-						const float4 c = a.sq.c[entry];
-						float4 e = a.E[slot];
-						e.x += c.x, e.y += c.y, e.z += c.z; // E += T * (...) * BRDF * emission
-						a.E[slot] = e;
-					}
+					if (!occluded) add_shadow_contribution( a.Es, a.E, slot, a.sq.c[entry] ); // E += T * (...) * BRDF * emission
 				}
 				else if (h.pos >= 0 || resumed) // a BVH primitive beat the analytic hit (a resumed ray's fields held its record)
 				{
@@ -276,6 +294,8 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 							entry = my;
 							const float4 ot = a.sq.o_t[entry], ds = a.sq.d_s[entry];
 							O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
+							resumed = ( slot & RESUME_BIT ) != 0, slot &= ~RESUME_BIT;
+							if (resumed) rec = __float_as_uint( a.sq.c[entry].w );
 						}
 						else
 						{
@@ -285,10 +305,11 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 							O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far
 							if (resumed) rec = __float_as_uint( dh.w ), a.st.meta[entry] &= ~META_SUSPENDED;
 						}
-						if (!ANY && resumed)
+						if (resumed)
 						{
 							const uint32_t* r = a.rec_in + (size_t)rec * a.rec_stride;
-							cur = r[0], sp = (int)r[1], k = (int)r[2], h.obj = (int)r[3], h.pos = (int)r[4];
+							cur = r[0], sp = (int)r[1], k = (int)r[2];
+							if (!ANY) h.obj = (int)r[3], h.pos = (int)r[4];
 							for (int i = 0; i < sp; i++) stack[i * BLOCK] = r[REC_HEADER + i];
 						}
 						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
@@ -299,7 +320,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 				}
 				if (exhausted) tail_steps = 0;
 			}
-			else if (!ANY && a.budget > 0 && tail_steps >= a.budget)
+			else if (a.budget > 0 && tail_steps >= a.budget)
 			{
 				// park the rays that are still walking
 				const bool want = has && cur != RT_DONE;
@@ -312,14 +333,36 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 					if (lane == leader) base = atomicAdd( a.n_rec_out, (uint32_t)__popcll( m ) );
 					const uint32_t idx = __shfl( base, leader, 64 ) + rank;
 					const bool park = want && idx < a.rec_cap; // no room: keep walking for another budget
+					uint32_t si = 0;
+					if (ANY) // the parked shadow rays join the next bounce's shadow queue
+					{
+						const unsigned long long mp = __ballot( park );
+						if (mp)
+						{
+							const int l2 = __ffsll( (long long)mp ) - 1;
+							uint32_t b2 = 0;
+							if (lane == l2) b2 = atomicAdd( a.n_shadow_out, (uint32_t)__popcll( mp ) );
+							si = __shfl( b2, l2, 64 ) + __builtin_amdgcn_mbcnt_hi( (uint32_t)( mp >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mp, 0 ) );
+						}
+					}
 					if (park)
 					{
 						uint32_t* r = a.rec_out + (size_t)idx * a.rec_stride;
 						r[0] = cur, r[1] = (uint32_t)sp, r[2] = (uint32_t)k, r[3] = (uint32_t)h.obj, r[4] = (uint32_t)h.pos;
 						for (int i = 0; i < sp; i++) r[REC_HEADER + i] = stack[i * BLOCK];
-						a.st.o_t[entry].w = h.t;
-						a.st.d_h[entry].w = __uint_as_float( idx );
-						a.st.meta[entry] |= META_SUSPENDED;
+						if (ANY)
+						{
+							const float4 c = a.sq.c[entry];
+							a.sq_out.o_t[si] = make_float4( O.x, O.y, O.z, h.t );
+							a.sq_out.d_s[si] = make_float4( D.x, D.y, D.z, __uint_as_float( slot | RESUME_BIT ) );
+							a.sq_out.c[si] = make_float4( c.x, c.y, c.z, __uint_as_float( idx ) );
+						}
+						else
+						{
+							a.st.o_t[entry].w = h.t;
+							a.st.d_h[entry].w = __uint_as_float( idx );
+							a.st.meta[entry] |= META_SUSPENDED;
+						}
 						has = false, inexact = false, nSusp++;
 						if (COUNT) maxSteps = steps > maxSteps ? steps : maxSteps, steps = 0;
 					}
@@ -366,7 +409,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	// ray is not a new ray
 	if (threadIdx.x == 0 && blockIdx.x == 0)
 	{
-		const uint32_t nres = ANY ? 0u : ( *a.n_rec_in < a.rec_cap ? *a.n_rec_in : a.rec_cap ); // resumed rays in this launch
+		const uint32_t nres = *a.n_rec_in < a.rec_cap ? *a.n_rec_in : a.rec_cap; // resumed rays in this launch
 		if (!ANY) atomicAdd( &ctr->extend_rays, (unsigned long long)( *a.rays_ptr - nres ) );
 		atomicAdd( ANY ? &ctr->shadow_walkers : &ctr->extend_walkers, (unsigned long long)( n - nres ) );
 	}
@@ -551,20 +594,25 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 __global__ void k_next_bounce( DevCounters* ctr, int consumed )
 {
 	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_extend = 0, ctr->pool_connect = 0;
-	ctr->n_rec[consumed ^ 1] = 0; // read by this bounce's walk, written again by the next bounce's
-	ctr->pending = ctr->n_state[consumed ^ 1];
+	ctr->n_rec[consumed ^ 1] = 0, ctr->n_srec[consumed ^ 1] = 0; // read by this bounce's walks, written again by the next bounce's
+	ctr->pending = ctr->n_state[consumed ^ 1] + ctr->n_shadow[consumed ^ 1];
 }
 
 // ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
-__global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E, int WH, int S )
+__global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E, const long long* __restrict__ Es, int WH, int S )
 {
 	const int p = blockIdx.x * BLOCK + threadIdx.x;
 	if (p >= WH) return;
 	float4 a = acc[p];
 	for (int k = 0; k < S; k++)
 	{
-		const float4 e = E[(size_t)k * WH + p];
-		a.x += e.x, a.y += e.y, a.z += e.z, a.w += 0.0f;
+		const size_t slot = (size_t)k * WH + p;
+		const float4 e = E[slot];
+		const longlong2 s01 = *(const longlong2*)( Es + 4 * slot );
+		const long long s2 = Es[4 * slot + 2];
+		const float inv = 1.0f / ES_SCALE;
+		// Sample() of this path = float chain + exactly summed walked-shadow contributions, then accumulator += Sample()
+		a.x += e.x + (float)s01.x * inv, a.y += e.y + (float)s01.y * inv, a.z += e.z + (float)s2 * inv, a.w += 0.0f;
 	}
 	acc[p] = a;
 }
@@ -838,11 +886,12 @@ struct rtmi_ctx
 	// path tracing state, sized for `batch` samples in flight
 	int batch = 0;
 	PathState st[2] = {};       // queue-ordered path state, ping-pong
-	ShadowQueue sq[2] = {};     // ping-pong
-	uint32_t* rec[2] = { 0, 0 }; // suspend records of k_trace<closest>, ping-pong
+	ShadowQueue sq[2] = {};     // ping-pong: the other one collects the shadow rays parked by k_trace<any>
+	uint32_t* rec[2] = { 0, 0 }, *srec[2] = { 0, 0 }; // suspend records of k_trace<closest> / <any>, ping-pong
+	long long* Es = 0;          // 4 x int64 per slot: exact sum of walked shadow contributions
 	uint32_t rec_cap = 0;
 	int rec_stride = 0;
-	int budget = 128;           // tail steps after which a still-walking ray is parked (0 = never)
+	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
 	float4* E = 0;              // radiance estimate per slot (sample_in_batch * W*H + pixel)
 	uint32_t* wq[2] = { 0, 0 }; // per state set: entries that walk the BVH
 	DevCounters* ctr = 0;
@@ -923,13 +972,13 @@ static void free_scene( rtmi_ctx* c )
 static void free_batch( rtmi_ctx* c )
 {
 	void* ps[] = { c->st[0].o_t, c->st[0].d_h, c->st[0].T_s, c->st[0].meta, c->st[1].o_t, c->st[1].d_h, c->st[1].T_s, c->st[1].meta,
-		c->sq[0].o_t, c->sq[0].d_s, c->sq[0].c, c->sq[1].o_t, c->sq[1].d_s, c->sq[1].c, c->E, c->wq[0], c->wq[1], c->rec[0], c->rec[1] };
+		c->sq[0].o_t, c->sq[0].d_s, c->sq[0].c, c->sq[1].o_t, c->sq[1].d_s, c->sq[1].c, c->E, c->Es, c->wq[0], c->wq[1], c->rec[0], c->rec[1], c->srec[0], c->srec[1] };
 	for (void* p : ps) if (p) (void)hipFree( p );
 	c->st[0] = c->st[1] = PathState{}, c->sq[0] = c->sq[1] = ShadowQueue{}, c->E = 0, c->wq[0] = c->wq[1] = 0, c->batch = 0;
-	c->rec[0] = c->rec[1] = 0, c->rec_cap = 0;
+	c->rec[0] = c->rec[1] = c->srec[0] = c->srec[1] = 0, c->rec_cap = 0, c->Es = 0;
 }
-// Queue state per path in flight: 2 x 52 B path state, 16 B E, 2 x 48 B shadow ray, 2 x 4 B walk index = 224 B, plus suspend
-// records for one path in eight (2 x (6 + stack depth) words each).
+// Queue state per path in flight: 2 x 52 B path state, 16 B E, 32 B Es, 2 x 48 B shadow ray, 2 x 4 B walk index = 256 B, plus
+// suspend records for one path in eight (4 x (6 + stack depth) words each).
 static int ensure_batch( rtmi_ctx* c, int S )
 {
 	if (c->batch >= S) return RTMI_OK;
@@ -940,9 +989,9 @@ static int ensure_batch( rtmi_ctx* c, int S )
 	int r = RTMI_OK;
 	for (int k = 0; k < 2 && !r; k++)
 		( r = dev_alloc( c, &c->st[k].o_t, n ) ) || ( r = dev_alloc( c, &c->st[k].d_h, n ) ) || ( r = dev_alloc( c, &c->st[k].T_s, n ) ) || ( r = dev_alloc( c, &c->st[k].meta, n ) ) ||
-			( r = dev_alloc( c, &c->wq[k], n ) ) || ( r = dev_alloc( c, &c->sq[k].o_t, n ) ) || ( r = dev_alloc( c, &c->sq[k].d_s, n ) ) || ( r = dev_alloc( c, &c->sq[k].c, n ) ) ||
-			( r = dev_alloc( c, &c->rec[k], cap * c->rec_stride ) );
-	if (!r) r = dev_alloc( c, &c->E, n );
+			( r = dev_alloc( c, &c->wq[k], n ) ) || ( r = dev_alloc( c, &c->sq[k].o_t, n + cap ) ) || ( r = dev_alloc( c, &c->sq[k].d_s, n + cap ) ) || ( r = dev_alloc( c, &c->sq[k].c, n + cap ) ) ||
+			( r = dev_alloc( c, &c->rec[k], cap * c->rec_stride ) ) || ( r = dev_alloc( c, &c->srec[k], cap * c->rec_stride ) );
+	if (!r) ( r = dev_alloc( c, &c->E, n ) ) || ( r = dev_alloc( c, &c->Es, 4 * n ) );
 	if (r) { free_batch( c ); return r; }
 	c->batch = S, c->rec_cap = (uint32_t)cap;
 	return RTMI_OK;
@@ -1239,10 +1288,12 @@ static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper, int bu
 	hipStream_t s = c->stream;
 	DevCounters* ctr = c->ctr;
 	TraceArgs a = {};
-	a.st = c->st[set], a.sq = c->sq[set], a.E = c->E, a.wq = c->wq[set];
+	a.st = c->st[set], a.sq = c->sq[set], a.sq_out = c->sq[set ^ 1], a.E = c->E, a.Es = c->Es, a.wq = c->wq[set];
 	a.count_ptr = any ? &ctr->n_shadow[set] : &ctr->n_walk[set], a.rays_ptr = &ctr->n_state[set];
 	a.pool = any ? &ctr->pool_connect : &ctr->pool_extend;
-	a.rec_in = c->rec[set ^ 1], a.rec_out = c->rec[set], a.n_rec_out = &ctr->n_rec[set], a.n_rec_in = &ctr->n_rec[set ^ 1];
+	a.rec_in = any ? c->srec[set ^ 1] : c->rec[set ^ 1], a.rec_out = any ? c->srec[set] : c->rec[set];
+	a.n_rec_out = any ? &ctr->n_srec[set] : &ctr->n_rec[set], a.n_rec_in = any ? &ctr->n_srec[set ^ 1] : &ctr->n_rec[set ^ 1];
+	a.n_shadow_out = &ctr->n_shadow[set ^ 1];
 	a.rec_cap = c->rec_cap, a.rec_stride = c->rec_stride, a.refill = c->refill, a.budget = budget;
 	ScopedTimer t( c, any ? 2 : 0 );
 	if (any)
@@ -1259,7 +1310,7 @@ static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper, int bu
 static void launch_primary( rtmi_ctx* c, uint32_t N, int sample_begin, int stride )
 {
 	ScopedTimer t( c, 1 );
-	hipLaunchKernelGGL( k_primary, dim3( nsblocks( N ) ), dim3( SBLOCK ), 0, c->stream, c->ds, c->st[0], c->E, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
+	hipLaunchKernelGGL( k_primary, dim3( nsblocks( N ) ), dim3( SBLOCK ), 0, c->stream, c->ds, c->st[0], c->E, (float4*)c->Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
 		c->seeds, sample_begin, stride, c->wq[0], c->ctr );
 }
 
@@ -1301,7 +1352,7 @@ static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
 	}
 	{
 		ScopedTimer t( c, 3 );
-		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, s, c->accum, c->E, WH, S );
+		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, s, c->accum, c->E, c->Es, WH, S );
 	}
 	HIPCHK( hipGetLastError() );
 	return RTMI_OK;
