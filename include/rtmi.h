@@ -130,7 +130,7 @@ int rtmi_set_accumulator( rtmi_ctx*, void* device_float4 );
  *        sample_begin, sample_begin+sample_stride, ... (sample_count of them)   -- renderer.cpp:246-365, 559-567
  *   other modes: accumulator[p] = Trace(primary ray p, 0) with recursion limit max_depth (renderer.cpp:133-244,
  *        578-592); sample_* ignored; anti_aliasing != 0 selects the 4-sample pattern of renderer.cpp:594-618.
- * Asynchronous on the handle's stream; any read-back call synchronises. */
+ * Asynchronous; any read-back call synchronises (see rtmi_flush). */
 int rtmi_render( rtmi_ctx*, int mode, int sample_begin, int sample_count, int sample_stride, int max_depth, int anti_aliasing );
 
 /* Parity hooks (no reference counterpart as an API; they expose Scene::FindNearest / Scene::IsOccluded,
@@ -148,6 +148,12 @@ int rtmi_postprocess( rtmi_ctx*, uint32_t* rgb8_inout, int width, int height, co
 /* accumulatorBuffer->CopyFromDevice equivalent: W*H*4 floats. */
 int rtmi_read_accumulator( rtmi_ctx*, float* rgba_out );
 int rtmi_synchronize( rtmi_ctx* );
+/* No reference counterpart (its queues are in-order and Tick blocks on every read-back, renderer.cpp:538-556).
+ * rtmi_render returns with work still enqueued on the handle's stream AND on internal streams (the tails of render
+ * batches overlap the next batches).  Every rtmi_* call that reads or resets the accumulator orders itself after that
+ * work; a caller that consumes a caller-owned accumulator (rtmi_set_accumulator) on its own stream calls rtmi_flush
+ * first: non-blocking, it makes the handle's stream wait for everything rendered so far. */
+int rtmi_flush( rtmi_ctx* );
 
 /* Counters and timing (the reference only prints a frame time, renderer.cpp:635-641). */
 int rtmi_set_profiling( rtmi_ctx*, int hip_event_timing, int count_nodes );

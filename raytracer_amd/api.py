@@ -121,7 +121,7 @@ def device_lib():
         L.rtmi_version.restype = C.c_char_p
         for name in ("rtmi_create", "rtmi_destroy", "rtmi_set_stream", "rtmi_upload_scene", "rtmi_set_camera", "rtmi_set_seeds", "rtmi_reset_accumulator",
                      "rtmi_set_accumulator", "rtmi_render", "rtmi_trace_primary", "rtmi_trace_rays", "rtmi_finalize", "rtmi_postprocess",
-                     "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats"):
+                     "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_flush", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats"):
             getattr(L, name).restype = C.c_int
         L.rtmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.rtmi_destroy.argtypes = [C.c_void_p]
@@ -138,6 +138,7 @@ def device_lib():
         L.rtmi_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(PostFx)]
         L.rtmi_read_accumulator.argtypes = [C.c_void_p, C.c_void_p]
         L.rtmi_synchronize.argtypes = [C.c_void_p]
+        L.rtmi_flush.argtypes = [C.c_void_p]
         L.rtmi_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rtmi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rtmi_reset_stats.argtypes = [C.c_void_p]
@@ -157,7 +158,7 @@ def host_lib():
         L.rth_scene_create.restype = C.c_void_p
         L.rth_scene_destroy.argtypes = [C.c_void_p]
         L.rth_scene_make_default.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
-        L.rth_scene_make_room.argtypes = [C.c_void_p]
+        L.rth_scene_make_room.argtypes = [C.c_void_p, C.c_float]
         L.rth_scene_add_sphere.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
         L.rth_scene_add_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(Material), C.c_float, C.c_float, C.c_float]
         L.rth_scene_add_torus_knot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
@@ -207,6 +208,8 @@ def host_lib():
 class HostScene:
     """rtmi::Scene (raytracer_amd/host/scene.h): primitives + host-built BVH + marshalled upload arrays."""
 
+    scale = 1.0
+
     def __init__(self, handle=None, owner=True):
         self.L = host_lib()
         self.h = handle if handle is not None else self.L.rth_scene_create()
@@ -224,8 +227,8 @@ class HostScene:
             raise RtmiError("default scene: assets not found in %s" % assets)
         return s
 
-    def make_room(self):
-        self.L.rth_scene_make_room(self.h)
+    def make_room(self, scale=1.0):
+        self.L.rth_scene_make_room(self.h, float(scale))
         return self
 
     def add_sphere(self, pos, r, mat):
@@ -260,16 +263,32 @@ class HostScene:
         return dict(zip(("quads", "spheres", "cubes", "planes", "triangles", "nodes_used", "max_depth"), out.tolist()))
 
 
-def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None):
+KNOT_LENGTH, KNOT_CIRCUMFERENCE = 6.2273, 0.47124  # centre line and tube circumference of the default (2,3) knot at scale 1
+
+
+def mesh_scale(n_tris_target, target_area=4e-4):
+    """Unit scale at which the mesh configs are built.  The reference's triangle test rejects |det| < 1e-4
+    (primitive.h:59): a triangle of area A is invisible to rays with 2*A*|cos| < 1e-4, so a mesh of N triangles needs
+    a total area of about N * 4e-4 to be seen at all.  Three knots have 8.8 m^2 at the reference room's scale; the
+    whole scene (room, light, knots, camera) is therefore built in units `scale` times larger.  1 for small meshes."""
+    area1 = 3 * KNOT_LENGTH * KNOT_CIRCUMFERENCE
+    return float(max(1, int(np.ceil((n_tris_target * target_area / area1) ** 0.5))))
+
+
+def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None, scale=None):
     """The mesh configs of SURVEY 8d: the reference room (6 planes + light quad) with three torus knots at
-    x = -1.5, 0, +1.5, z = 1.5 (the monkeys' places, scene.h:80-82): diffuse red, mirror, glass n=1.52.
-    n_tris_target is the total triangle count aimed for (nu = nv = sqrt(n/6))."""
-    s = HostScene().make_room()
+    x = -1.5, 0, +1.5, z = 1.5 (the monkeys' places, scene.h:80-82): diffuse red, mirror, glass n=1.52, everything
+    multiplied by mesh_scale(n) (see there; use default_camera(w, h, scene.scale) with it).  n_tris_target is the
+    total triangle count aimed for; the tessellation is isotropic (segments along : around = length : circumference)."""
+    k = mesh_scale(n_tris_target) if scale is None else float(scale)
+    s = HostScene().make_room(k)
+    s.scale = k
     s.load_logo()
-    n = max(8, int(round((n_tris_target / 6.0) ** 0.5)))
+    nv = max(3, int(round((n_tris_target / 6.0 / (KNOT_LENGTH / KNOT_CIRCUMFERENCE)) ** 0.5)))
+    nu = max(8, int(round(n_tris_target / 6.0 / nv)))
     mats = materials or [Material(DIFFUSE, (0.93, 0.21, 0.21)), Material(MIRROR, (0.93, 0.93, 0.93)), Material(GLASS, (0.93, 0.93, 0.93), 1.52)]
     for m, x in zip(mats, (-1.5, 0.0, 1.5)):
-        s.add_torus_knot(n, n, (x, 0.0, 1.5), m)
+        s.add_torus_knot(nu, nv, (x * k, 0.0, 1.5 * k), m, 0.42 * k, 0.17 * k, 0.075 * k)
     return s.finalize(builder)
 
 
@@ -279,10 +298,11 @@ def seed_table(n):
     return out
 
 
-def default_camera(w, h):
+def default_camera(w, h, scale=1.0):
+    """camera.h:20-23 as 4 x float4 (pos, topLeft, topRight, bottomLeft); `scale` moves it with a scaled scene"""
     cam = np.zeros(16, np.float32)
     host_lib().rth_camera_default(w, h, _ptr(cam))
-    return cam
+    return cam * np.float32(scale)
 
 
 class Device:
@@ -339,6 +359,10 @@ class Device:
 
     def sync(self):
         self._chk(self.L.rtmi_synchronize(self.h))
+
+    def flush(self):
+        """non-blocking: the handle's stream waits for everything rendered so far (before using a caller-owned accumulator)"""
+        self._chk(self.L.rtmi_flush(self.h))
 
     def trace_primary(self):
         obj = np.zeros(self.W * self.H, np.int32)

@@ -415,8 +415,128 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	}
 }
 
-// ---- shade: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361), fused with the creation of the next
-// ray and of the shadow ray: their analytic intersections and root box tests run here, so that a bounce is
+// ---- one path vertex: Renderer::Sample loop body after FindNearest (renderer.cpp:254-361) --------------------------
+// In: the ray (O, D), its hit (t, obj), the path's throughput T, rng state, flags.  Adds a light hit to E[slot].
+// Out: the next ray (push_next) and the NEE shadow ray (shadow_any) with its contribution.
+struct Vertex
+{
+	bool push_next, shadow_any;
+	f3 newO, newD, shO, shD, contrib;
+	float shT;
+};
+__device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float t, int obj, f3& T, uint32_t& rng, uint32_t& flags, float4* __restrict__ E, uint32_t slot, Vertex& v )
+{
+	v.push_next = false, v.shadow_any = false, v.shT = 0;
+	if (obj == -1) return; // miss: the path ends, Sample returns E (renderer.cpp:254, 363)
+	const f3 I = O + t * D;
+	HitAttr a;
+	hit_attributes( s, obj, I, D, a );
+	const f3 N = a.N;
+	const int type = a.mat->type;
+	if (type == RTMI_LIGHT)
+	{
+		if (flags & FLAG_SPECULAR) // renderer.cpp:262-263: E + T * emission
+		{
+			const f3 add = T * mk3( s.light_emission );
+			float4 e = E[slot];
+			e.x = e.x + add.x, e.y = e.y + add.y, e.z = e.z + add.z;
+			E[slot] = e;
+		}
+		return;
+	}
+	if (type == RTMI_MIRROR) // renderer.cpp:266-271
+	{
+		const f3 refl = D - ( 2 * dot3( D, N ) ) * N;
+		v.newO = I + refl * 0.001f, v.newD = refl;
+		flags = FLAG_SPECULAR, v.push_next = true;
+		return;
+	}
+	if (type == RTMI_GLASS) // renderer.cpp:272-321
+	{
+		const float air = 1.0003f, ior = a.mat->ior;
+		float n1, n2;
+		f3 absorption = mk3( 1, 1, 1 );
+		if (flags & FLAG_INSIDE)
+		{
+			const float4 ab = a.mat->absorption;
+			absorption = mk3( expf( -ab.x * t ), expf( -ab.y * t ), expf( -ab.z * t ) );
+			n1 = ior, n2 = air;
+		}
+		else n1 = air, n2 = ior;
+		const float ratio = n1 / n2;
+		const float inc = dot3( N, -D );
+		const float k = 1.0f - sqrf_( ratio ) * ( 1.0f - sqrf_( inc ) );
+		const f3 refr = ratio * D + N * ( ratio * inc - sqrtf( k ) );
+		const float outc = dot3( -N, refr );
+		const double left = sqrf_( ( n1 * inc - ior * outc ) / ( n1 * inc + n2 * outc ) );
+		const double right = sqrf_( ( n1 * outc - ior * inc ) / ( n1 * outc + n2 * inc ) );
+		const float Fr = (float)( 0.5 * ( left + right ) );
+		T = T * ( a.albedo * absorption );
+		bool reflect = k < 0;
+		if (!reflect) reflect = rng_float( rng ) <= Fr; // short-circuit: no draw when k < 0
+		if (reflect)
+		{
+			const f3 refl = D - ( 2.0f * dot3( D, N ) ) * N;
+			v.newO = I + refl * 0.001f, v.newD = refl, flags = FLAG_SPECULAR;
+		}
+		else v.newO = I + refr * 0.001f, v.newD = refr, flags = FLAG_SPECULAR | FLAG_INSIDE; // renderer.cpp:317-318
+		v.push_next = true;
+	}
+	else // diffuse (and SUBSTANCE), renderer.cpp:322-361
+	{
+		const f3 BRDF = a.albedo / 3.14159265358979323846264f;
+		// Scene::RandomPointOnLight, scene.h:317-341
+		const f3 c1 = mk3( s.light_c1 ), c2 = mk3( s.light_c2 ), c3 = mk3( s.light_c3 ), Nl = mk3( s.light_N );
+		const f3 c1c2 = normalize3( c1 - c2 );
+		float len = rng_float( rng ) * s.light_s;
+		const f3 u = c1c2 * len;
+		const f3 c2c3 = normalize3( c3 - c2 );
+		len = rng_float( rng ) * s.light_s;
+		const f3 w = c2c3 * len;
+		const f3 lp = c2 + u + w - mk3( 0, 0.01f, 0 );
+		f3 L = lp - I;
+		const float dist = magnitude3( L );
+		L = normalize3( L );
+		if (dot3( N, L ) > 0 && dot3( Nl, -L ) > 0)
+		{
+			const float solidAngle = ( dot3( Nl, -L ) * s.light_A ) / sqrf_( dist );
+			const float lightPDF = 1.0f / solidAngle;
+			v.contrib = T * ( dot3( N, L ) / lightPDF ) * BRDF * mk3( s.light_emission );
+			v.shO = I + L * 0.001f, v.shD = L, v.shT = dist - 2.0f * 0.001f;
+			v.shadow_any = true;
+		}
+		// Russian roulette, renderer.cpp:347-352 (template clamp = fmaxf(a, fminf(f, b)) with ternaries)
+		float p = smax( a.albedo.z, smax( a.albedo.x, a.albedo.y ) );
+		p = p < 1.0f ? p : 1.0f;
+		p = 0.0f > p ? 0.0f : p;
+		if (!( p < rng_float( rng ) ))
+		{
+			T = T * ( 1.0f / p );
+			// Scene::DiffuseReflection, scene.h:517-532 (draw order x, y, z)
+			f3 R;
+			do
+			{
+				const float rx = rng_float( rng ) * 2.0f - 1.0f;
+				const float ry = rng_float( rng ) * 2.0f - 1.0f;
+				const float rz = rng_float( rng ) * 2.0f - 1.0f;
+				R = mk3( rx, ry, rz );
+			} while (magnitude3( R ) > 1.0f);
+			R = normalize3( R );
+			if (dot3( N, R ) < 0) R = -R;
+			const float hemiPDF = 1.0f / ( 3.14159265358979323846264f * 2.0f );
+			v.newO = I + R * 0.001f, v.newD = R;
+			T = T * ( ( dot3( N, R ) / hemiPDF ) * BRDF );
+			flags = 0, v.push_next = true;
+		}
+	}
+	// A path whose throughput is exactly zero can never change E again (every later term is T * finite): ending it here
+	// returns the same bits as following it.  The reference has no such test and follows glass-trapped paths for the
+	// ~1400 interactions it takes 0.93^n to underflow, and then for as long as they stay trapped (renderer.cpp:306).
+	if (T.x == 0.0f && T.y == 0.0f && T.z == 0.0f) v.push_next = false;
+}
+
+// ---- shade kernel: shade_vertex fused with the creation of the next ray and of the shadow ray: their analytic
+// intersections and root box tests run here, so that a bounce is
 //   k_trace<closest>  ->  k_shade  ->  k_trace<any>
 // and rays that never reach the BVH cost no queue traffic at all. ------------------------------------------------------
 __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ n_in,
@@ -427,10 +547,10 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 	__syncthreads();
 	const uint32_t i = blockIdx.x * SBLOCK + threadIdx.x;
 	const uint32_t n = *n_in;
-	bool push_next = false, walk_next = false, shadow_any = false, push_shadow = false, parked = false;
+	bool walk_next = false, push_shadow = false, parked = false;
 	uint32_t slot = 0, flags = 0, rng = 0;
-	f3 newO, newD, shO, shD, contrib, T;
-	float shT = 0;
+	f3 T;
+	Vertex v; v.push_next = false, v.shadow_any = false, v.shT = 0;
 	RayHit nh; nh.t = 1e34f, nh.obj = -1, nh.pos = -1;
 	if (i < n)
 	{
@@ -445,137 +565,39 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 		{
 			// the closest-hit walk of this path is not finished (k_trace parked it): hand the entry on unchanged; t holds
 			// the best distance so far and the object field the index of its suspend record
-			newO = O, newD = D, nh.t = t, nh.obj = obj, push_next = true, walk_next = true;
+			v.newO = O, v.newD = D, nh.t = t, nh.obj = obj, v.push_next = true, walk_next = true;
 		}
-		else if (obj != -1)
+		else
 		{
-			const f3 I = O + t * D;
-			HitAttr a;
-			hit_attributes( s, obj, I, D, a );
-			const f3 N = a.N;
-			const int type = a.mat->type;
-			if (type == RTMI_LIGHT)
+			shade_vertex( s, O, D, t, obj, T, rng, flags, E, slot, v );
+			// the rays created here start their life here: everything of FindNearest / IsOccluded before the BVH walk
+			if (v.push_next) walk_next = begin_closest( s, v.newO, v.newD, nh );
+			if (v.shadow_any)
 			{
-				if (flags & FLAG_SPECULAR) // renderer.cpp:262-263: E + T * emission
+				bool occluded;
+				begin_any( s, v.shO, v.shD, v.shT, occluded, push_shadow );
+				if (!occluded && !push_shadow) // unoccluded without a walk: E += contribution now (renderer.cpp:343)
 				{
-					const f3 add = T * mk3( s.light_emission );
 					float4 e = E[slot];
-					e.x = e.x + add.x, e.y = e.y + add.y, e.z = e.z + add.z;
+					e.x += v.contrib.x, e.y += v.contrib.y, e.z += v.contrib.z;
 					E[slot] = e;
 				}
 			}
-			else if (type == RTMI_MIRROR) // renderer.cpp:266-271
-			{
-				const f3 refl = D - ( 2 * dot3( D, N ) ) * N;
-				newO = I + refl * 0.001f, newD = refl;
-				flags = FLAG_SPECULAR, push_next = true;
-			}
-			else if (type == RTMI_GLASS) // renderer.cpp:272-321
-			{
-				const float air = 1.0003f, ior = a.mat->ior;
-				float n1, n2;
-				f3 absorption = mk3( 1, 1, 1 );
-				if (flags & FLAG_INSIDE)
-				{
-					const float4 ab = a.mat->absorption;
-					absorption = mk3( expf( -ab.x * t ), expf( -ab.y * t ), expf( -ab.z * t ) );
-					n1 = ior, n2 = air;
-				}
-				else n1 = air, n2 = ior;
-				const float ratio = n1 / n2;
-				const float inc = dot3( N, -D );
-				const float k = 1.0f - sqrf_( ratio ) * ( 1.0f - sqrf_( inc ) );
-				const f3 refr = ratio * D + N * ( ratio * inc - sqrtf( k ) );
-				const float outc = dot3( -N, refr );
-				const double left = sqrf_( ( n1 * inc - ior * outc ) / ( n1 * inc + n2 * outc ) );
-				const double right = sqrf_( ( n1 * outc - ior * inc ) / ( n1 * outc + n2 * inc ) );
-				const float Fr = (float)( 0.5 * ( left + right ) );
-				T = T * ( a.albedo * absorption );
-				bool reflect = k < 0;
-				if (!reflect) reflect = rng_float( rng ) <= Fr; // short-circuit: no draw when k < 0
-				if (reflect)
-				{
-					const f3 refl = D - ( 2.0f * dot3( D, N ) ) * N;
-					newO = I + refl * 0.001f, newD = refl, flags = FLAG_SPECULAR;
-				}
-				else newO = I + refr * 0.001f, newD = refr, flags = FLAG_SPECULAR | FLAG_INSIDE; // renderer.cpp:317-318
-				push_next = true;
-			}
-			else // diffuse (and SUBSTANCE), renderer.cpp:322-361
-			{
-				const f3 BRDF = a.albedo / 3.14159265358979323846264f;
-				// Scene::RandomPointOnLight, scene.h:317-341
-				const f3 c1 = mk3( s.light_c1 ), c2 = mk3( s.light_c2 ), c3 = mk3( s.light_c3 ), Nl = mk3( s.light_N );
-				const f3 c1c2 = normalize3( c1 - c2 );
-				float len = rng_float( rng ) * s.light_s;
-				const f3 u = c1c2 * len;
-				const f3 c2c3 = normalize3( c3 - c2 );
-				len = rng_float( rng ) * s.light_s;
-				const f3 v = c2c3 * len;
-				const f3 lp = c2 + u + v - mk3( 0, 0.01f, 0 );
-				f3 L = lp - I;
-				const float dist = magnitude3( L );
-				L = normalize3( L );
-				if (dot3( N, L ) > 0 && dot3( Nl, -L ) > 0)
-				{
-					const float solidAngle = ( dot3( Nl, -L ) * s.light_A ) / sqrf_( dist );
-					const float lightPDF = 1.0f / solidAngle;
-					contrib = T * ( dot3( N, L ) / lightPDF ) * BRDF * mk3( s.light_emission );
-					shO = I + L * 0.001f, shD = L, shT = dist - 2.0f * 0.001f;
-					shadow_any = true;
-				}
-				// Russian roulette, renderer.cpp:347-352 (template clamp = fmaxf(a, fminf(f, b)) with ternaries)
-				float p = smax( a.albedo.z, smax( a.albedo.x, a.albedo.y ) );
-				p = p < 1.0f ? p : 1.0f;
-				p = 0.0f > p ? 0.0f : p;
-				if (!( p < rng_float( rng ) ))
-				{
-					T = T * ( 1.0f / p );
-					// Scene::DiffuseReflection, scene.h:517-532 (draw order x, y, z)
-					f3 R;
-					do
-					{
-						const float rx = rng_float( rng ) * 2.0f - 1.0f;
-						const float ry = rng_float( rng ) * 2.0f - 1.0f;
-						const float rz = rng_float( rng ) * 2.0f - 1.0f;
-						R = mk3( rx, ry, rz );
-					} while (magnitude3( R ) > 1.0f);
-					R = normalize3( R );
-					if (dot3( N, R ) < 0) R = -R;
-					const float hemiPDF = 1.0f / ( 3.14159265358979323846264f * 2.0f );
-					newO = I + R * 0.001f, newD = R;
-					T = T * ( ( dot3( N, R ) / hemiPDF ) * BRDF );
-					flags = 0, push_next = true;
-				}
-			}
-		}
-		// the rays created here start their life here: everything of FindNearest / IsOccluded before the BVH walk
-		if (push_next && !parked) walk_next = begin_closest( s, newO, newD, nh );
-		if (shadow_any)
-		{
-			bool occluded;
-			begin_any( s, shO, shD, shT, occluded, push_shadow );
-			if (!occluded && !push_shadow) // unoccluded without a walk: E += contribution now (renderer.cpp:343)
-			{
-				float4 e = E[slot];
-				e.x += contrib.x, e.y += contrib.y, e.z += contrib.z;
-				E[slot] = e;
-			}
 		}
 	}
 	{
-		const unsigned long long m = __ballot( shadow_any );
+		const unsigned long long m = __ballot( v.shadow_any );
 		if (( threadIdx.x & 63 ) == 0 && m) atomicAdd( &lds[48], (uint32_t)__popcll( m ) );
 	}
-	const bool push[3] = { push_next, walk_next, push_shadow };
+	const bool push[3] = { v.push_next, walk_next, push_shadow };
 	uint32_t* const counters[3] = { n_out, n_walk_out, n_shadow };
 	uint32_t idx[3];
 	block_append<3>( push, counters, idx, lds );
-	if (push_next)
+	if (v.push_next)
 	{
 		const uint32_t j = idx[0];
-		out.o_t[j] = make_float4( newO.x, newO.y, newO.z, nh.t );
-		out.d_h[j] = make_float4( newD.x, newD.y, newD.z, __int_as_float( nh.obj ) );
+		out.o_t[j] = make_float4( v.newO.x, v.newO.y, v.newO.z, nh.t );
+		out.d_h[j] = make_float4( v.newD.x, v.newD.y, v.newD.z, __int_as_float( nh.obj ) );
 		out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
 		out.meta[j] = slot | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u );
 		if (walk_next) wq_out[idx[1]] = j | ( parked ? RESUME_BIT : 0u );
@@ -583,11 +605,103 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 	if (push_shadow)
 	{
 		const uint32_t si = idx[2];
-		sq.o_t[si] = make_float4( shO.x, shO.y, shO.z, shT );
-		sq.d_s[si] = make_float4( shD.x, shD.y, shD.z, __uint_as_float( slot ) );
-		sq.c[si] = make_float4( contrib.x, contrib.y, contrib.z, 0 );
+		sq.o_t[si] = make_float4( v.shO.x, v.shO.y, v.shO.z, v.shT );
+		sq.d_s[si] = make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot ) );
+		sq.c[si] = make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 );
 	}
 	if (threadIdx.x == 0 && lds[48]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[48] );
+}
+
+// ---- tail: once only a few thousand paths are alive a bounce is pure latency (three launches, each as long as one
+// ray's walk), and paths trapped inside the mirror or glass object live for thousands of bounces (the reference has
+// no bounce limit, renderer.cpp:251).  This kernel runs each remaining path for up to `max_bounces` bounces in one
+// launch: one lane per path loops FindNearest -> shade_vertex -> IsOccluded.  Paths still alive are written compacted
+// to the other state set for the next round, so that a round's waves are dense again (nearly every wave of the first
+// round holds one long path, and a thousand almost-empty resident waves would starve the next batches' bulk kernels).
+// Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
+// when the host switches over or on the round lengths. ------------------------------------------------------------------
+__global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathState out, float4* __restrict__ E, long long* __restrict__ Es, const uint32_t* __restrict__ n_in,
+	uint32_t* n_out, int max_bounces, int per_wave, DevCounters* ctr )
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t* stack = lds_stack + threadIdx.x;
+	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane: a wave full of long paths pays for the divergence
+	// of 64 different walks at every bounce, a wave with a few of them runs each at close to single-lane latency
+	const uint32_t stride = 64u / (uint32_t)per_wave;
+	const uint32_t i = blockIdx.x * (uint32_t)per_wave + threadIdx.x / stride;
+	const uint32_t n = *n_in;
+	if (blockIdx.x * (uint32_t)per_wave >= n) return; // wave-uniform
+	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	bool alive = false;
+	uint32_t slot = 0, flags = 0, rng = 0;
+	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), T = mk3( 0, 0, 0 );
+	if (i < n && threadIdx.x % stride == 0)
+	{
+		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
+		const uint32_t meta = in.meta[i];
+		slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w );
+		O = mk3( ot ), D = mk3( dh ), T = mk3( ts );
+		alive = true;
+		for (int nb = 0; nb < max_bounces; nb++)
+		{
+			// Scene::FindNearest from scratch (the analytic part stored with the entry is recomputed: same bits)
+			RayHit h;
+			const bool walk = begin_closest( s, O, D, h );
+			nExt++;
+			if (walk)
+			{
+				nExtWalk++;
+				const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+				const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+				if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, 64, tc );
+				else traverse<false, false, false>( s, O, D, rD, h, stack, 64, tc );
+			}
+			Vertex v;
+			shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, E, slot, v );
+			if (v.shadow_any)
+			{
+				nSh++;
+				bool occluded, swalk;
+				begin_any( s, v.shO, v.shD, v.shT, occluded, swalk );
+				if (!occluded && !swalk)
+				{
+					float4 e = E[slot];
+					e.x += v.contrib.x, e.y += v.contrib.y, e.z += v.contrib.z;
+					E[slot] = e;
+				}
+				else if (swalk)
+				{
+					nShWalk++;
+					RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
+					const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
+					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+					const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, 64, tc ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, 64, tc );
+					if (!occ) add_shadow_contribution( Es, E, slot, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
+				}
+			}
+			if (!v.push_next) { alive = false; break; }
+			O = v.newO, D = v.newD;
+		}
+	}
+	// survivors of this round, compacted (one atomic per wave)
+	const unsigned long long m = __ballot( alive );
+	if (m)
+	{
+		const int leader = __ffsll( (long long)m ) - 1;
+		uint32_t base = 0;
+		if ((int)threadIdx.x == leader) base = atomicAdd( n_out, (uint32_t)__popcll( m ) );
+		const uint32_t j = __shfl( base, leader, 64 ) + __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) );
+		if (alive)
+		{
+			out.o_t[j] = make_float4( O.x, O.y, O.z, 1e34f );
+			out.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( -1 ) );
+			out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+			out.meta[j] = slot | ( flags << 30 );
+		}
+	}
+	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
+	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
 }
 
 // end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
@@ -866,6 +980,30 @@ __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int
 // =================================================================================================================
 // host side
 // =================================================================================================================
+// One render batch in flight.  The bulk bounces of a batch run on the handle's stream; its tail (k_tail: the last paths,
+// some of which live for thousands of bounces) and its k_accumulate run on the slot's own stream, so that they overlap
+// the bulk bounces of the following batches.  k_accumulate launches are chained by events in batch order (the
+// accumulator sums samples in sample order, renderer.cpp:566-567).
+#define MAX_SLOTS 8
+struct BatchSlot
+{
+	int batch = 0;              // capacity in samples
+	PathState st[2] = {};       // queue-ordered path state, ping-pong
+	ShadowQueue sq[2] = {};     // ping-pong: the other one collects the shadow rays parked by k_trace<any>
+	uint32_t* wq[2] = { 0, 0 }; // per state set: entries that walk the BVH
+	uint32_t* rec[2] = { 0, 0 }, *srec[2] = { 0, 0 }; // suspend records of k_trace<closest> / <any>, ping-pong
+	float4* E = 0;              // radiance estimate per slot index (sample_in_batch * W*H + pixel)
+	long long* Es = 0;          // 4 x int64 per slot index: exact sum of walked shadow contributions
+	uint32_t rec_cap = 0;
+	int rec_stride = 0;
+	DevCounters* ctr = 0;
+	uint32_t* host_counts = 0;  // pinned ring of read-back queue lengths
+	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
+	hipStream_t tail_stream = 0;
+	hipEvent_t bulk_done = 0, acc_done = 0;
+	bool busy = false;          // acc_done has been recorded and not yet waited for by a new user of the slot
+};
+
 struct rtmi_ctx
 {
 	int device = 0, W = 0, H = 0;
@@ -883,20 +1021,14 @@ struct rtmi_ctx
 	float4* accum_own = 0;
 	float4* accum = 0;
 	uint32_t* pixels = 0, *pixels2 = 0, *gamma_lut = 0;
-	// path tracing state, sized for `batch` samples in flight
-	int batch = 0;
-	PathState st[2] = {};       // queue-ordered path state, ping-pong
-	ShadowQueue sq[2] = {};     // ping-pong: the other one collects the shadow rays parked by k_trace<any>
-	uint32_t* rec[2] = { 0, 0 }, *srec[2] = { 0, 0 }; // suspend records of k_trace<closest> / <any>, ping-pong
-	long long* Es = 0;          // 4 x int64 per slot: exact sum of walked shadow contributions
-	uint32_t rec_cap = 0;
-	int rec_stride = 0;
+	// path tracing: up to MAX_SLOTS render batches in flight (see BatchSlot)
+	BatchSlot slots[MAX_SLOTS];
+	int n_slots = 6, next_slot = 0;
+	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
+	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
+	int tail_lanes = 4;          // paths per wave in the tail rounds after the first (power of two <= 64)
+	bool log_bounces = false;   // RTMI_LOG_BOUNCES: print the path count per bounce (diagnostics)
 	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
-	float4* E = 0;              // radiance estimate per slot (sample_in_batch * W*H + pixel)
-	uint32_t* wq[2] = { 0, 0 }; // per state set: entries that walk the BVH
-	DevCounters* ctr = 0;
-	uint32_t* host_counts = 0; // pinned ring of read-back queue lengths
-	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
 	WFrame* frames = 0;
 	int frames_depth = 0;
 	// stats / profiling
@@ -943,8 +1075,9 @@ static hipEvent_t get_event( rtmi_ctx* c )
 struct ScopedTimer // records a pair of events around a launch when profiling is on
 {
 	rtmi_ctx* c; int cls; hipEvent_t a = 0, b = 0;
-	ScopedTimer( rtmi_ctx* c, int cls ) : c( c ), cls( cls ) { if (c->prof_events) { a = get_event( c ), b = get_event( c ); (void)hipEventRecord( a, c->stream ); } }
-	~ScopedTimer() { if (c->prof_events) { (void)hipEventRecord( b, c->stream ); c->timed.push_back( { a, b, cls } ); } }
+	hipStream_t st;
+	ScopedTimer( rtmi_ctx* c, int cls, hipStream_t on = 0 ) : c( c ), cls( cls ), st( on ? on : c->stream ) { if (c->prof_events) { a = get_event( c ), b = get_event( c ); (void)hipEventRecord( a, st ); } }
+	~ScopedTimer() { if (c->prof_events) { (void)hipEventRecord( b, st ); c->timed.push_back( { a, b, cls } ); } }
 };
 static void resolve_timers( rtmi_ctx* c )
 {
@@ -969,31 +1102,49 @@ static void free_scene( rtmi_ctx* c )
 	c->scene_allocs.clear();
 	c->has_scene = false;
 }
-static void free_batch( rtmi_ctx* c )
+static void free_batch( BatchSlot& b )
 {
-	void* ps[] = { c->st[0].o_t, c->st[0].d_h, c->st[0].T_s, c->st[0].meta, c->st[1].o_t, c->st[1].d_h, c->st[1].T_s, c->st[1].meta,
-		c->sq[0].o_t, c->sq[0].d_s, c->sq[0].c, c->sq[1].o_t, c->sq[1].d_s, c->sq[1].c, c->E, c->Es, c->wq[0], c->wq[1], c->rec[0], c->rec[1], c->srec[0], c->srec[1] };
+	void* ps[] = { b.st[0].o_t, b.st[0].d_h, b.st[0].T_s, b.st[0].meta, b.st[1].o_t, b.st[1].d_h, b.st[1].T_s, b.st[1].meta,
+		b.sq[0].o_t, b.sq[0].d_s, b.sq[0].c, b.sq[1].o_t, b.sq[1].d_s, b.sq[1].c, b.E, b.Es, b.wq[0], b.wq[1], b.rec[0], b.rec[1], b.srec[0], b.srec[1] };
 	for (void* p : ps) if (p) (void)hipFree( p );
-	c->st[0] = c->st[1] = PathState{}, c->sq[0] = c->sq[1] = ShadowQueue{}, c->E = 0, c->wq[0] = c->wq[1] = 0, c->batch = 0;
-	c->rec[0] = c->rec[1] = c->srec[0] = c->srec[1] = 0, c->rec_cap = 0, c->Es = 0;
+	b.st[0] = b.st[1] = PathState{}, b.sq[0] = b.sq[1] = ShadowQueue{}, b.E = 0, b.wq[0] = b.wq[1] = 0, b.batch = 0;
+	b.rec[0] = b.rec[1] = b.srec[0] = b.srec[1] = 0, b.rec_cap = 0, b.Es = 0;
 }
+static void free_batches( rtmi_ctx* c ) { for (auto& b : c->slots) free_batch( b ); } // callers have synchronised the device
 // Queue state per path in flight: 2 x 52 B path state, 16 B E, 32 B Es, 2 x 48 B shadow ray, 2 x 4 B walk index = 256 B, plus
 // suspend records for one path in eight (4 x (6 + stack depth) words each).
-static int ensure_batch( rtmi_ctx* c, int S )
+static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 {
-	if (c->batch >= S) return RTMI_OK;
-	free_batch( c );
+	if (b.batch >= S) return RTMI_OK;
+	if (b.busy) { (void)hipEventSynchronize( b.acc_done ); b.busy = false; }
+	free_batch( b );
 	const size_t n = (size_t)S * c->W * c->H;
 	const size_t cap = n / 8 + 1024;
-	c->rec_stride = c->stack_depth + REC_HEADER;
+	b.rec_stride = c->stack_depth + REC_HEADER;
 	int r = RTMI_OK;
 	for (int k = 0; k < 2 && !r; k++)
-		( r = dev_alloc( c, &c->st[k].o_t, n ) ) || ( r = dev_alloc( c, &c->st[k].d_h, n ) ) || ( r = dev_alloc( c, &c->st[k].T_s, n ) ) || ( r = dev_alloc( c, &c->st[k].meta, n ) ) ||
-			( r = dev_alloc( c, &c->wq[k], n ) ) || ( r = dev_alloc( c, &c->sq[k].o_t, n + cap ) ) || ( r = dev_alloc( c, &c->sq[k].d_s, n + cap ) ) || ( r = dev_alloc( c, &c->sq[k].c, n + cap ) ) ||
-			( r = dev_alloc( c, &c->rec[k], cap * c->rec_stride ) ) || ( r = dev_alloc( c, &c->srec[k], cap * c->rec_stride ) );
-	if (!r) ( r = dev_alloc( c, &c->E, n ) ) || ( r = dev_alloc( c, &c->Es, 4 * n ) );
-	if (r) { free_batch( c ); return r; }
-	c->batch = S, c->rec_cap = (uint32_t)cap;
+		( r = dev_alloc( c, &b.st[k].o_t, n ) ) || ( r = dev_alloc( c, &b.st[k].d_h, n ) ) || ( r = dev_alloc( c, &b.st[k].T_s, n ) ) || ( r = dev_alloc( c, &b.st[k].meta, n ) ) ||
+			( r = dev_alloc( c, &b.wq[k], n ) ) || ( r = dev_alloc( c, &b.sq[k].o_t, n + cap ) ) || ( r = dev_alloc( c, &b.sq[k].d_s, n + cap ) ) || ( r = dev_alloc( c, &b.sq[k].c, n + cap ) ) ||
+			( r = dev_alloc( c, &b.rec[k], cap * b.rec_stride ) ) || ( r = dev_alloc( c, &b.srec[k], cap * b.rec_stride ) );
+	if (!r) ( r = dev_alloc( c, &b.E, n ) ) || ( r = dev_alloc( c, &b.Es, 4 * n ) );
+	if (r) { free_batch( b ); return r; }
+	b.batch = S, b.rec_cap = (uint32_t)cap;
+	return RTMI_OK;
+}
+// Everything enqueued by earlier rtmi_render calls (tails and accumulates on the slot streams) happens-before what is
+// enqueued on the handle's stream after this call.
+static int join_batches( rtmi_ctx* c )
+{
+	if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
+	return RTMI_OK;
+}
+
+// host-blocking: the handle's stream and every slot stream are idle afterwards
+static int sync_all( rtmi_ctx* c )
+{
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	for (int k = 0; k < MAX_SLOTS; k++) if (c->slots[k].tail_stream) { HIPCHK( hipStreamSynchronize( c->slots[k].tail_stream ) ); c->slots[k].busy = false; }
+	c->last_acc = 0;
 	return RTMI_OK;
 }
 
@@ -1018,20 +1169,39 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties( &prop, device_id ) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-		const char* e = getenv( "RTMI_STEP_BUDGET" );
+		c->log_bounces = getenv( "RTMI_LOG_BOUNCES" ) != 0;
+		// batches in flight: each uses its own stream, and streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES,
+		// 4 unless the process raises it before HIP starts) serialise behind each other
+		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
+		c->n_slots = ( q && atoi( q ) >= 7 ) ? 6 : 4;
+		const char* e = getenv( "RTMI_TAIL_LANES" );
+		if (e) { const int v = atoi( e ); if (v >= 1 && v <= 64 && ( v & ( v - 1 ) ) == 0) c->tail_lanes = v; }
+		e = getenv( "RTMI_SLOTS" );
+		if (e && atoi( e ) >= 1 && atoi( e ) <= MAX_SLOTS) c->n_slots = atoi( e );
+		e = getenv( "RTMI_TAIL_PATHS" );
+		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );
+		e = getenv( "RTMI_STEP_BUDGET" );
 		if (e && atoi( e ) >= 0) c->budget = atoi( e );
 		e = getenv( "RTMI_REFILL" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= 64) c->refill = atoi( e );
 	}
 	const size_t n = (size_t)width * height;
 	if (dev_alloc( c, &c->seeds, n ) || dev_alloc( c, &c->accum_own, n ) || dev_alloc( c, &c->pixels, n ) || dev_alloc( c, &c->pixels2, n ) ||
-		dev_alloc( c, &c->gamma_lut, 256 ) || dev_alloc( c, &c->ctr, 1 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+		dev_alloc( c, &c->gamma_lut, 256 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
 	c->accum = c->accum_own;
-	if (hipHostMalloc( (void**)&c->host_counts, 4 * sizeof( uint32_t ), hipHostMallocDefault ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
-	for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags( &c->count_ev[i], hipEventDisableTiming ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_HIP; }
+	for (int k = 0; k < c->n_slots; k++)
+	{
+		BatchSlot& b = c->slots[k];
+		if (dev_alloc( c, &b.ctr, 1 ) || hipHostMalloc( (void**)&b.host_counts, 4 * sizeof( uint32_t ), hipHostMallocDefault ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+		// (a low-priority stream would suit the tails, but a run with hipStreamCreateWithPriority stopped making progress here)
+		bool ok = hipStreamCreateWithFlags( &b.tail_stream, hipStreamNonBlocking ) == hipSuccess;
+		for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags( &b.count_ev[i], hipEventDisableTiming ) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags( &b.bulk_done, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.acc_done, hipEventDisableTiming ) == hipSuccess;
+		if (!ok) { rtmi_destroy( c ); return RTMI_ERR_HIP; }
+		(void)hipMemset( b.ctr, 0, sizeof( DevCounters ) );
+	}
 	(void)hipMemset( c->accum_own, 0, n * sizeof( float4 ) );
 	(void)hipMemset( c->seeds, 0, n * sizeof( uint32_t ) );
-	(void)hipMemset( c->ctr, 0, sizeof( DevCounters ) );
 	// default camera, camera.h:20-23
 	const float aspect = (float)width / (float)height;
 	c->cam.pos = make_float4( 0, 0, -2, 0 ), c->cam.tl = make_float4( -aspect, 1, 0, 0 ), c->cam.tr = make_float4( aspect, 1, 0, 0 ), c->cam.bl = make_float4( -aspect, -1, 0, 0 );
@@ -1045,11 +1215,18 @@ int rtmi_destroy( rtmi_ctx* c )
 	(void)hipSetDevice( c->device );
 	(void)hipDeviceSynchronize();
 	resolve_timers( c );
-	free_scene( c ), free_batch( c );
-	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->ctr, c->frames };
+	free_scene( c ), free_batches( c );
+	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->frames };
 	for (void* p : ps) if (p) (void)hipFree( p );
-	if (c->host_counts) (void)hipHostFree( c->host_counts );
-	for (int i = 0; i < 4; i++) if (c->count_ev[i]) (void)hipEventDestroy( c->count_ev[i] );
+	for (auto& b : c->slots)
+	{
+		if (b.ctr) (void)hipFree( b.ctr );
+		if (b.host_counts) (void)hipHostFree( b.host_counts );
+		for (int i = 0; i < 4; i++) if (b.count_ev[i]) (void)hipEventDestroy( b.count_ev[i] );
+		if (b.bulk_done) (void)hipEventDestroy( b.bulk_done );
+		if (b.acc_done) (void)hipEventDestroy( b.acc_done );
+		if (b.tail_stream) (void)hipStreamDestroy( b.tail_stream );
+	}
 	for (auto e : c->ev_pool) (void)hipEventDestroy( e );
 	if (c->own_stream) (void)hipStreamDestroy( c->own_stream );
 	delete c;
@@ -1059,7 +1236,8 @@ int rtmi_destroy( rtmi_ctx* c )
 int rtmi_set_stream( rtmi_ctx* c, void* s )
 {
 	if (!c) return RTMI_ERR_INVALID;
-	HIPCHK( hipStreamSynchronize( c->stream ) );
+	int r = sync_all( c );
+	if (r) return r;
 	c->stream = s ? (hipStream_t)s : c->own_stream;
 	return RTMI_OK;
 }
@@ -1068,9 +1246,17 @@ int rtmi_synchronize( rtmi_ctx* c )
 {
 	if (!c) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
-	HIPCHK( hipStreamSynchronize( c->stream ) );
+	int r = sync_all( c );
+	if (r) return r;
 	resolve_timers( c );
 	return RTMI_OK;
+}
+
+int rtmi_flush( rtmi_ctx* c )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	return join_batches( c );
 }
 
 // Validates the reference-layout node array and repacks it: pair k = nodes[3+2k], nodes[4+2k] (the reference
@@ -1079,7 +1265,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 {
 	if (!c || !d) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
-	HIPCHK( hipStreamSynchronize( c->stream ) );
+	{ int r = sync_all( c ); if (r) return r; }
 	if (d->n_quads < 0 || d->n_spheres < 0 || d->n_cubes < 0 || d->n_planes < 0 || d->n_triangles < 0) return fail( c, RTMI_ERR_INVALID, "negative primitive count" );
 	const int nbvh = d->n_spheres + d->n_triangles;
 	const long long total = (long long)d->n_quads + d->n_spheres + d->n_cubes + d->n_planes + d->n_triangles;
@@ -1233,7 +1419,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	ds.wl_intensity = d->whitted_intensity;
 
 	free_scene( c );
-	free_batch( c ); // the suspend records are sized by the stack depth
+	free_batches( c ); // the suspend records are sized by the stack depth
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
 	{
@@ -1265,13 +1451,14 @@ int rtmi_reset_accumulator( rtmi_ctx* c )
 {
 	if (!c) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; } // accumulates still in flight come first
 	HIPCHK( hipMemsetAsync( c->accum, 0, (size_t)c->W * c->H * sizeof( float4 ), c->stream ) );
 	return RTMI_OK;
 }
 int rtmi_set_accumulator( rtmi_ctx* c, void* p )
 {
 	if (!c) return RTMI_ERR_INVALID;
-	HIPCHK( hipStreamSynchronize( c->stream ) );
+	{ int r = sync_all( c ); if (r) return r; }
 	c->accum = p ? (float4*)p : c->accum_own;
 	return RTMI_OK;
 }
@@ -1282,19 +1469,19 @@ static inline int nsblocks( size_t n ) { return (int)( ( n + SBLOCK - 1 ) / SBLO
 // persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need
 static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); }
 
-static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper, int budget )
+static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t upper, int budget )
 {
 	const size_t lds = stack_bytes( c );
 	hipStream_t s = c->stream;
-	DevCounters* ctr = c->ctr;
+	DevCounters* ctr = b.ctr;
 	TraceArgs a = {};
-	a.st = c->st[set], a.sq = c->sq[set], a.sq_out = c->sq[set ^ 1], a.E = c->E, a.Es = c->Es, a.wq = c->wq[set];
+	a.st = b.st[set], a.sq = b.sq[set], a.sq_out = b.sq[set ^ 1], a.E = b.E, a.Es = b.Es, a.wq = b.wq[set];
 	a.count_ptr = any ? &ctr->n_shadow[set] : &ctr->n_walk[set], a.rays_ptr = &ctr->n_state[set];
 	a.pool = any ? &ctr->pool_connect : &ctr->pool_extend;
-	a.rec_in = any ? c->srec[set ^ 1] : c->rec[set ^ 1], a.rec_out = any ? c->srec[set] : c->rec[set];
+	a.rec_in = any ? b.srec[set ^ 1] : b.rec[set ^ 1], a.rec_out = any ? b.srec[set] : b.rec[set];
 	a.n_rec_out = any ? &ctr->n_srec[set] : &ctr->n_rec[set], a.n_rec_in = any ? &ctr->n_srec[set ^ 1] : &ctr->n_rec[set ^ 1];
 	a.n_shadow_out = &ctr->n_shadow[set ^ 1];
-	a.rec_cap = c->rec_cap, a.rec_stride = c->rec_stride, a.refill = c->refill, a.budget = budget;
+	a.rec_cap = b.rec_cap, a.rec_stride = b.rec_stride, a.refill = c->refill, a.budget = budget;
 	ScopedTimer t( c, any ? 2 : 0 );
 	if (any)
 	{
@@ -1307,68 +1494,107 @@ static void launch_trace( rtmi_ctx* c, bool any, int set, uint32_t upper, int bu
 		else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 }
-static void launch_primary( rtmi_ctx* c, uint32_t N, int sample_begin, int stride )
+static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
 {
 	ScopedTimer t( c, 1 );
-	hipLaunchKernelGGL( k_primary, dim3( nsblocks( N ) ), dim3( SBLOCK ), 0, c->stream, c->ds, c->st[0], c->E, (float4*)c->Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
-		c->seeds, sample_begin, stride, c->wq[0], c->ctr );
+	hipLaunchKernelGGL( k_primary, dim3( nsblocks( N ) ), dim3( SBLOCK ), 0, c->stream, c->ds, b.st[0], b.E, (float4*)b.Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
+		c->seeds, sample_begin, stride, b.wq[0], b.ctr );
 }
 
-// one batch of S samples: ray generation over all S*W*H slots, then queue-driven bounces until the queue is empty
-static int render_batch( rtmi_ctx* c, int sample_begin, int S, int stride )
+// One batch of S samples.  On the handle's stream: ray generation over all S*W*H slots, then queue-driven bounces until
+// few paths are left.  On the slot's stream, after the bulk: k_tail runs the remaining paths to their ends, then
+// k_accumulate (after the previous batch's).  The call returns with all of it enqueued.
+static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride )
 {
 	const int WH = c->W * c->H;
 	const uint32_t N = (uint32_t)( (size_t)S * WH );
 	hipStream_t s = c->stream;
-	DevCounters* ctr = c->ctr;
+	DevCounters* ctr = b.ctr;
+	if (b.busy) { HIPCHK( hipStreamWaitEvent( s, b.acc_done, 0 ) ); b.busy = false; } // the slot's previous batch is done with these buffers
 	HIPCHK( hipMemsetAsync( ctr, 0, 64, s ) ); // queue lengths and pools
-	launch_primary( c, N, sample_begin, stride );
+	launch_primary( c, b, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
 	int cur = 0;        // state / shadow queue set of this bounce
+	int clean = 0;      // bounces launched without parking since the path count fell under 4 * tail_paths
+	bool tail = false;
 	for (int bounce = 0;; bounce++)
 	{
-		launch_trace( c, false, cur, upper, c->budget );
+		// Near the end of the bulk: stop parking rays (so that no suspended state is left), one bounce later hand the
+		// remaining paths to k_tail.
+		const bool prep = c->tail_paths && upper <= 4ull * c->tail_paths;
+		if (c->tail_paths && upper <= c->tail_paths && clean >= 1) { tail = true; break; }
+		const int budget = prep ? 0 : c->budget;
+		clean = prep ? clean + 1 : 0;
+		launch_trace( c, b, false, cur, upper, budget );
 		{
 			ScopedTimer t( c, 1 );
-			hipLaunchKernelGGL( k_shade, dim3( nsblocks( upper ) ), dim3( SBLOCK ), 0, s, c->ds, c->st[cur], c->st[cur ^ 1], c->sq[cur], c->E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
-				c->wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
+			hipLaunchKernelGGL( k_shade, dim3( nsblocks( upper ) ), dim3( SBLOCK ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], b.E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
+				b.wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
-		launch_trace( c, true, cur, upper, c->budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
+		launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
 		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
 		c->stats.bounce_launches++;
 		// read back what the next bounce starts with (paths + carried shadow rays); it is looked at two iterations later
 		const int slot = bounce & 3;
-		HIPCHK( hipMemcpyAsync( &c->host_counts[slot], &ctr->pending, 4, hipMemcpyDeviceToHost, s ) );
-		HIPCHK( hipEventRecord( c->count_ev[slot], s ) );
+		HIPCHK( hipMemcpyAsync( &b.host_counts[slot], &ctr->pending, 4, hipMemcpyDeviceToHost, s ) );
+		HIPCHK( hipEventRecord( b.count_ev[slot], s ) );
+		cur ^= 1;
 		if (bounce >= 2)
 		{
 			const int old = ( bounce - 2 ) & 3;
-			HIPCHK( hipEventSynchronize( c->count_ev[old] ) );
-			upper = std::min( upper, c->host_counts[old] );
+			HIPCHK( hipEventSynchronize( b.count_ev[old] ) );
+			upper = std::min( upper, b.host_counts[old] );
+			if (c->log_bounces && ( bounce < 64 || ( bounce & ( bounce - 1 ) ) == 0 )) fprintf( stderr, "rtmi: bounce %d starts with %u paths\n", bounce - 1, b.host_counts[old] );
 		}
 		if (upper == 0) break;
-		cur ^= 1;
 	}
+	// the rest of the batch runs beside the next batches' bulk
+	hipStream_t ts = b.tail_stream;
+	HIPCHK( hipEventRecord( b.bulk_done, s ) );
+	HIPCHK( hipStreamWaitEvent( ts, b.bulk_done, 0 ) );
+	if (tail)
 	{
-		ScopedTimer t( c, 3 );
-		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, s, c->accum, c->E, c->Es, WH, S );
+		// rounds of 32, 64, 128, ... bounces, enqueued blind (a round over an empty queue returns at once); survivors are
+		// compacted between rounds; the last round has no limit
+		ScopedTimer t( c, 3, ts );
+		const size_t lds = (size_t)c->stack_depth * 64 * sizeof( uint32_t );
+		for (int round = 0, len = 32; round <= 11; round++, len *= 2)
+		{
+			const int limit = round == 11 ? 0x7FFFFFFF : len;
+			const int per = round == 0 ? 64 : c->tail_lanes; // the first round is throughput work (most paths end in it)
+			hipLaunchKernelGGL( k_tail, dim3( ( upper + per - 1 ) / per ), dim3( 64 ), lds, ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, per, ctr );
+			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur );
+			cur ^= 1;
+		}
+		c->stats.bounce_launches++;
 	}
+	if (c->last_acc) HIPCHK( hipStreamWaitEvent( ts, c->last_acc, 0 ) ); // accumulate in batch order
+	{
+		ScopedTimer t( c, 3, ts );
+		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, ts, c->accum, b.E, b.Es, WH, S );
+	}
+	HIPCHK( hipEventRecord( b.acc_done, ts ) );
+	b.busy = true, c->last_acc = b.acc_done;
 	HIPCHK( hipGetLastError() );
 	return RTMI_OK;
 }
 
 static int fetch_counters( rtmi_ctx* c )
 {
-	DevCounters h;
-	HIPCHK( hipMemcpyAsync( &h, c->ctr, sizeof( h ), hipMemcpyDeviceToHost, c->stream ) );
-	HIPCHK( hipStreamSynchronize( c->stream ) );
-	c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
-	c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
-	c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
-	c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
-	c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
-	HIPCHK( hipMemsetAsync( c->ctr, 0, sizeof( DevCounters ), c->stream ) );
+	int r = sync_all( c );
+	if (r) return r;
+	for (int k = 0; k < c->n_slots; k++)
+	{
+		DevCounters h;
+		HIPCHK( hipMemcpy( &h, c->slots[k].ctr, sizeof( h ), hipMemcpyDeviceToHost ) );
+		c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
+		c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
+		c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
+		c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
+		c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
+		HIPCHK( hipMemset( c->slots[k].ctr, 0, sizeof( DevCounters ) ) );
+	}
 	return RTMI_OK;
 }
 
@@ -1385,18 +1611,23 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
 		const char* env = getenv( "RTMI_BATCH" );
 		if (env && atoi( env ) > 0) S = std::min( sample_count, atoi( env ) );
-		int r = ensure_batch( c, S );
-		if (r) return r;
+		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
+		for (int k = 0; k < c->n_slots; k++) { int r = ensure_batch( c, c->slots[k], S ); if (r) return r; }
 		for (int done = 0; done < sample_count; done += S)
 		{
 			const int n = std::min( S, sample_count - done );
-			if (( r = render_batch( c, sample_begin + done * sample_stride, n, sample_stride ) )) return r;
+			BatchSlot& b = c->slots[c->next_slot]; // batches rotate over the slots so that one's tail overlaps the next one's bulk
+			c->next_slot = ( c->next_slot + 1 ) % c->n_slots;
+			int r = ensure_batch( c, b, S );
+			if (r) return r;
+			if (( r = render_batch( c, b, sample_begin + done * sample_stride, n, sample_stride ) )) return r;
 		}
 		// counters are folded into the stats lazily (rtmi_get_stats), no sync here
 		return RTMI_OK;
 	}
 	if (mode < 0 || mode > RTMI_PATHTRACING) return fail( c, RTMI_ERR_INVALID, "unknown mode" );
 	if (max_depth < 1 || max_depth > 64) return fail( c, RTMI_ERR_INVALID, "max_depth must be 1..64" );
+	{ int r = join_batches( c ); if (r) return r; } // this mode overwrites the accumulator
 	if (c->frames_depth < max_depth)
 	{
 		if (c->frames) (void)hipFree( c->frames ), c->frames = 0;
@@ -1418,16 +1649,18 @@ int rtmi_trace_primary( rtmi_ctx* c, int32_t* obj_out, float* t_out )
 	if (!c || !obj_out || !t_out) return RTMI_ERR_INVALID;
 	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_trace_primary before rtmi_upload_scene" );
 	HIPCHK( hipSetDevice( c->device ) );
-	int r = ensure_batch( c, 1 );
+	BatchSlot& b = c->slots[0];
+	int r = ensure_batch( c, b, 1 );
 	if (r) return r;
+	if (b.busy) { HIPCHK( hipStreamWaitEvent( c->stream, b.acc_done, 0 ) ); b.busy = false; }
 	const int WH = c->W * c->H;
 	int* dobj = 0; float* dt = 0;
 	if (( r = dev_alloc( c, &dobj, WH ) )) return r;
 	if (( r = dev_alloc( c, &dt, WH ) )) { (void)hipFree( dobj ); return r; }
-	hipError_t e0 = hipMemsetAsync( c->ctr, 0, 64, c->stream );
-	launch_primary( c, (uint32_t)WH, 0, 1 );
-	launch_trace( c, false, 0, (uint32_t)WH, 0 ); // no step budget: every ray finishes in this launch
-	hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, c->stream, c->st[0], WH, dobj, dt );
+	hipError_t e0 = hipMemsetAsync( b.ctr, 0, 64, c->stream );
+	launch_primary( c, b, (uint32_t)WH, 0, 1 );
+	launch_trace( c, b, false, 0, (uint32_t)WH, 0 ); // no step budget: every ray finishes in this launch
+	hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, c->stream, b.st[0], WH, dobj, dt );
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e3 = hipStreamSynchronize( c->stream );
@@ -1484,6 +1717,7 @@ int rtmi_finalize( rtmi_ctx* c, uint32_t* out, int frames, const rtmi_postfx* fx
 {
 	if (!c || !out) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; }
 	const int n = c->W * c->H;
 	{
 		ScopedTimer t( c, 3 );
@@ -1518,6 +1752,7 @@ int rtmi_read_accumulator( rtmi_ctx* c, float* out )
 {
 	if (!c || !out) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; }
 	HIPCHK( hipMemcpyAsync( out, c->accum, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	return RTMI_OK;

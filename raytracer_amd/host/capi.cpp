@@ -18,7 +18,7 @@ static Material to_mat( const rth_material* m )
 void* rth_scene_create() { return new Scene(); }
 void rth_scene_destroy( void* s ) { delete (Scene*)s; }
 int rth_scene_make_default( void* s, const char* assets, int builder ) { return ( (Scene*)s )->MakeDefault( assets, (BVH::Builder)builder ) ? 0 : -1; }
-void rth_scene_make_room( void* s ) { ( (Scene*)s )->MakeRoom(); }
+void rth_scene_make_room( void* s, float scale ) { ( (Scene*)s )->MakeRoom( scale ); }
 void rth_scene_add_sphere( void* s, float x, float y, float z, float r, const rth_material* m ) { ( (Scene*)s )->AddSphere( float3( x, y, z ), r, to_mat( m ) ); }
 void rth_scene_add_triangles( void* s, const float* v9, long long n, const rth_material* m, float ox, float oy, float oz )
 {

@@ -30,19 +30,24 @@ void Scene::AddTriangles( const float* v, size_t count, const Material& m, float
 		vt.push_back( Triangle( 0, float3( v[0], v[1], v[2] ) + off, float3( v[3], v[4], v[5] ) + off, float3( v[6], v[7], v[8] ) + off, m ) );
 }
 
-void Scene::MakeRoom()
+// scale 1 is the reference room.  The reference's triangle test rejects |det| < 1e-4 (primitive.h:59), i.e. every
+// triangle with 2 * area * |cos(angle to the ray)| < 1e-4: a 10^6-triangle mesh that fits the reference room
+// (three objects of ~3 m^2 each) is invisible to every ray.  The mesh configs therefore use the SAME scene in larger
+// units: room, light, objects and camera multiplied by `scale` (solid angles, hence the image, are unchanged).
+void Scene::MakeRoom( float scale )
 {
 	InitMaterials();
+	const float k = scale;
 	// scene.h:51-52, 58: light quad; scene.h:70-75: the six walls
-	mat4 M1base = mat4::Translate( float3( 0, 2.6f, 2 ) );
-	mat4 M1 = M1base * mat4::RotateZ( sinf( 0 * 0.6f ) * 0.1f ) * mat4::Translate( float3( 0, -0.9, 0 ) );
-	AddQuad( 3, light_mat, M1 );
-	AddPlane( float3( 1, 0, 0 ), 3, mirror_mat );
-	AddPlane( float3( -1, 0, 0 ), 2.99f, def_mat );
-	AddPlane( float3( 0, 1, 0 ), 1, def_mat );
-	AddPlane( float3( 0, -1, 0 ), 2, def_mat );
-	AddPlane( float3( 0, 0, 1 ), 3, def_mat );
-	AddPlane( float3( 0, 0, -1 ), 3.99f, def_mat );
+	mat4 M1base = mat4::Translate( float3( 0, 2.6f * k, 2 * k ) );
+	mat4 M1 = M1base * mat4::RotateZ( sinf( 0 * 0.6f ) * 0.1f ) * mat4::Translate( float3( 0, -0.9 * k, 0 ) );
+	AddQuad( 3 * k, light_mat, M1 );
+	AddPlane( float3( 1, 0, 0 ), 3 * k, mirror_mat );
+	AddPlane( float3( -1, 0, 0 ), 2.99f * k, def_mat );
+	AddPlane( float3( 0, 1, 0 ), 1 * k, def_mat );
+	AddPlane( float3( 0, -1, 0 ), 2 * k, def_mat );
+	AddPlane( float3( 0, 0, 1 ), 3 * k, def_mat );
+	AddPlane( float3( 0, 0, -1 ), 3.99f * k, def_mat );
 }
 
 bool Scene::MakeDefault( const std::string& assets, BVH::Builder builder )

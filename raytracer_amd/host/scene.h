@@ -23,7 +23,7 @@ public:
 	// the hard-coded scene of Scene::Scene() (scene.h:42-84): light quad, 2 spheres, cube, 6 planes, 3 x monkey.obj
 	bool MakeDefault( const std::string& assetsDir, BVH::Builder builder = BVH::REFERENCE_SAH );
 	// the 6-plane room + light quad only (no spheres/cube meshes); used by the mesh configs
-	void MakeRoom();
+	void MakeRoom( float scale = 1.0f );
 
 	void AddQuad( float s, const Material& m, const mat4& T );
 	void AddSphere( float3 p, float r, const Material& m );

@@ -22,9 +22,9 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-def room_rays(n, seed):
+def room_rays(n, seed, scale=1.0):
     rng = np.random.default_rng(seed)
-    O = np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1).astype(np.float32)
+    O = (np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1) * scale).astype(np.float32)
     D = rng.normal(size=(n, 3)).astype(np.float32)
     D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
     D[: n // 50, rng.integers(0, 3)] = 0  # zero direction components
@@ -37,15 +37,16 @@ def test_mesh_scene_matches_oracle(builder):
     W, H = 160, 90
     scene = api.mesh_scene(20000, builder)
     orc = Oracle(scene.desc)
-    cam, seeds = api.default_camera(W, H), api.seed_table(W * H)
+    cam, seeds = api.default_camera(W, H, scene.scale), api.seed_table(W * H)
     d = api.Device(W, H)
     d.upload(scene.desc)
     d.set_seeds(seeds)
+    d.set_camera(cam)
     obj, t = d.trace_primary()
     o_obj, o_t = orc.primary_hits(W, H, cam)
     assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
-    assert (obj >= 10).mean() > 0.02  # the knots are in view
-    O, Dr = room_rays(30000, 3)
+    assert (obj >= 7).mean() > 0.03  # the knots are in view (object ids: 1 quad, 6 planes, then triangles)
+    O, Dr = room_rays(30000, 3, scene.scale)
     tmax = np.full(len(O), 1e34, np.float32)
     g_obj, g_t = d.trace_rays(O, Dr, tmax)
     c_obj, c_t = orc.find_nearest(O, Dr, tmax)
@@ -90,10 +91,12 @@ def full():
     """BASELINE.json configs[2]: ~1M triangles at 1920x1080"""
     W, H = 1920, 1080
     scene = api.mesh_scene(1000000, api.BINNED_SAH)
+    assert scene.scale == 7.0  # three knots of 333k triangles each are only visible in units >= 7x the reference room's
     d = api.Device(W, H)
     d.upload(scene.desc)
     seeds = api.seed_table(W * H)
     d.set_seeds(seeds)
+    d.set_camera(api.default_camera(W, H, scene.scale))
     yield scene, d, seeds
     d.close()
 
@@ -102,8 +105,11 @@ def test_full_size_primary_hits_bit_exact(full):
     scene, d, _ = full
     obj, t = d.trace_primary()
     orc = Oracle(scene.desc)
-    o_obj, o_t = orc.primary_hits(1920, 1080, api.default_camera(1920, 1080))
+    o_obj, o_t = orc.primary_hits(1920, 1080, api.default_camera(1920, 1080, scene.scale))
     assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+    mats = scene.desc.arrays()["material_type"]
+    seen = np.unique(mats[obj[obj >= 7]])
+    assert (obj >= 7).mean() > 0.03 and set(seen.tolist()) == {api.DIFFUSE, api.MIRROR, api.GLASS}  # all three knots are hit
 
 
 def test_full_size_image_and_properties(full):
@@ -112,7 +118,7 @@ def test_full_size_image_and_properties(full):
     d.reset()
     d.render(api.PATHTRACING, 0, 1, 1)
     one = d.accumulator()
-    ref = Oracle(scene.desc).sample(W, H, api.default_camera(W, H), seeds, 0, 1)
+    ref = Oracle(scene.desc).sample(W, H, api.default_camera(W, H, scene.scale), seeds, 0, 1)
     assert rmse(one[..., :3], ref[..., :3]) <= 1e-5  # bar 1e-3
     # determinism: queue order changes from run to run, per-path results must not
     d.reset()
