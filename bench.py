@@ -67,12 +67,24 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
-                    help="HBM bytes per k_extend launch from a separate rocprofv3 --pmc run (profiles/), else null")
+                    help="HBM bytes per k_trace<closest> launch; default: the committed result of the separate rocprofv3 --pmc "
+                         "passes (profiles/r01_traffic.json, tools/profile_gpu.sh + tools/traffic.py), null if absent")
     return ap.parse_args()
+
+
+def committed_traffic():
+    """PMC counters cannot be collected inside this run (rocprofv3 --pmc is its own pass); use the committed figure."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return float(json.load(f)["kernels"]["k_trace<closest>"]["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
     a = parse()
+    if a.traffic_bytes_per_launch is None:
+        a.traffic_bytes_per_launch = committed_traffic()
     import torch
     import torch.distributed as dist
     from raytracer_amd import api

@@ -8,7 +8,7 @@ import re
 import sys
 from collections import defaultdict
 
-KERNELS = ("k_primary", "k_trace_rays", "k_trace", "k_shade", "k_accumulate", "k_finalize", "k_whitted", "k_next_bounce", "k_copy_hits",
+KERNELS = ("k_primary", "k_trace_rays", "k_trace", "k_tail", "k_shade", "k_accumulate", "k_finalize", "k_whitted", "k_next_bounce", "k_copy_hits",
            "k_gamma", "k_chroma", "k_vignette")
 
 
@@ -41,7 +41,7 @@ def main(out):
         print("%-28s %8d %12.1f %10.2f %10.2f %10.1f %6.1f" % (k, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / total))
     print("\n== longest dispatches (us, grid, vgpr, lds) ==")
     for k in sorted(per):
-        if k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_primary"):
+        if k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_primary") or k.startswith("k_tail"):
             top = sorted(per[k], reverse=True)[:4]
             print("%-28s " % k + "  ".join("%.0f/%s/%s/%s" % t for t in top))
     for sub in sorted(os.listdir(out)):
