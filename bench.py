@@ -99,7 +99,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace loop has no CPU path (see oracle/ for the checker)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path as N ranks)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -124,7 +125,7 @@ def main():
         D.render_split(lambda b, n, st: dev.render(api.PATHTRACING, b, n, st), i * spp * world, spp * world, rank, world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -151,8 +152,7 @@ def main():
     for i in range(a.steps):
         step(i)
     dev.flush()  # the tails of the last batches run on the library's own streams: order the reduce after them
-    if world > 1:
-        D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once
+    D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once (no-op for one rank)
     pixels = dev.finalize(a.steps * spp * world) if rank == 0 else None
     barrier()
     dt = time.perf_counter() - t0
@@ -161,7 +161,7 @@ def main():
 
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     rays = torch.tensor([st["extend_rays"] + st["shadow_rays"], st["extend_rays"], st["shadow_rays"], st["primary_samples"]], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     dt = float(tt.item())
@@ -196,7 +196,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, seeds, a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
