@@ -34,8 +34,8 @@ import time
 
 # librtmi keeps several render batches in flight, one stream each (the long tails of a batch overlap the bulk of the next
 # ones); HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 on the GPU box) and reads that variable when the
-# runtime is loaded.  With fewer than 8, run the benchmark in a child process that starts with 8 (nothing has touched the
-# GPU at this point) and leave with the child's exit code.  (Under rocprofv3 export GPU_MAX_HW_QUEUES=8 beforehand, as
+# runtime is loaded.  With fewer than 16, run the benchmark in a child process that starts with 16 (nothing has touched the
+# GPU at this point) and leave with the child's exit code.  (Under rocprofv3 export GPU_MAX_HW_QUEUES=16 beforehand, as
 # tools/profile_gpu.sh does, so that the profiled program is this one.)
 def _hw_queues():
     try:
@@ -44,9 +44,9 @@ def _hw_queues():
         return 4
 
 
-if __name__ == "__main__" and _hw_queues() < 8:
+if __name__ == "__main__" and _hw_queues() < 16:
     import subprocess
-    sys.exit(subprocess.call([sys.executable] + sys.argv, env=dict(os.environ, GPU_MAX_HW_QUEUES="8")))
+    sys.exit(subprocess.call([sys.executable] + sys.argv, env=dict(os.environ, GPU_MAX_HW_QUEUES="16")))
 
 import numpy as np
 
@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64, help="samples per pixel per step per GPU (configs[2]: 64 spp progressive)")
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -212,12 +212,13 @@ def cpu_baseline(scene, W, H, seeds, budget_s):
         orc.set_threads(min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
     cores = orc.max_threads()
     cam = api.default_camera(W, H, scene.scale)
-    # calibrate on every 64th row, then size the sample to about budget_s: a row subset of one sample when a whole
-    # frame is too slow, else several whole samples per pixel
+    # calibrate on every 16th row (twice: the first call also starts the OpenMP threads), then size the sample to about
+    # budget_s: a row subset of one sample when a whole frame is too slow, else several whole samples per pixel
     c = np.zeros(7, np.uint64)
-    t0 = time.perf_counter()
     orc.sample_rows(W, H, cam, seeds, 0, 1, 1, 0, 64, None, c)
-    per_row = (time.perf_counter() - t0) / len(range(0, H, 64))
+    t0 = time.perf_counter()
+    orc.sample_rows(W, H, cam, seeds, 0, 1, 1, 0, 16, None, c)
+    per_row = (time.perf_counter() - t0) / len(range(0, H, 16))
     frame_s = H * per_row
     row_step = max(1, int(np.ceil(frame_s / budget_s)))
     n_spp = max(1, int(budget_s / frame_s)) if row_step == 1 else 1

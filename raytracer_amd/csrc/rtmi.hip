@@ -58,7 +58,8 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 	uint32_t pool_extend;  // next unclaimed entry of the running k_trace<closest> launch (persistent waves pull chunks from it)
 	uint32_t pool_connect; // same for k_trace<any>
 	uint32_t pending;      // paths + carried shadow rays that the next bounce starts with (host loop termination)
-	uint32_t pad[3];
+	uint32_t pool_tail;    // next unclaimed entry of the running k_tail round
+	uint32_t pad[2];
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
 	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
 };
@@ -146,7 +147,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 	const uint32_t* __restrict__ seeds, int sample_begin, int sample_stride, uint32_t* __restrict__ wq, DevCounters* ctr )
 {
 	__shared__ uint32_t lds[16];
-	const uint32_t i = blockIdx.x * SBLOCK + threadIdx.x;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool walk = false;
 	if (i < N)
 	{
@@ -539,13 +540,13 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 // intersections and root box tests run here, so that a bounce is
 //   k_trace<closest>  ->  k_shade  ->  k_trace<any>
 // and rays that never reach the BVH cost no queue traffic at all. ------------------------------------------------------
-__global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ n_in,
+__global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, uint32_t* __restrict__ wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {
 	__shared__ uint32_t lds[3 * 16 + 1];
 	if (threadIdx.x == 0) lds[48] = 0;
 	__syncthreads();
-	const uint32_t i = blockIdx.x * SBLOCK + threadIdx.x;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n = *n_in;
 	bool walk_next = false, push_shadow = false, parked = false;
 	uint32_t slot = 0, flags = 0, rng = 0;
@@ -621,85 +622,97 @@ __global__ __launch_bounds__( SBLOCK ) void k_shade( DScene s, PathState in, Pat
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
 __global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathState out, float4* __restrict__ E, long long* __restrict__ Es, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, int per_wave, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
-	uint32_t* stack = lds_stack + threadIdx.x;
-	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane: a wave full of long paths pays for the divergence
-	// of 64 different walks at every bounce, a wave with a few of them runs each at close to single-lane latency
-	const uint32_t stride = 64u / (uint32_t)per_wave;
-	const uint32_t i = blockIdx.x * (uint32_t)per_wave + threadIdx.x / stride;
+	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
+	// of 64 different walks at every bounce (about 2.4x the latency per bounce); a wave with a few of them runs each at close
+	// to single-lane latency but issues a whole wave instruction for 4 lanes: with 4 per wave throughout, the tails of this
+	// scene (8 M path-bounces per 16-spp batch, 4 % of the bulk's) issued 42 % of all vector instructions on the chip and
+	// the next batches' bulk kernels ran 1.6x longer beside them.  So the round decides from its live path count: full waves
+	// while thousands are alive (throughput), 16 and then min_lanes per wave for the last few hundred (latency).
+	// The grid is a bounded number of resident waves that pull per_wave paths at a time.
 	const uint32_t n = *n_in;
-	if (blockIdx.x * (uint32_t)per_wave >= n) return; // wave-uniform
+	const int per_wave = n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
+	const uint32_t stride = 64u / (uint32_t)per_wave;
+	uint32_t* stack = lds_stack + threadIdx.x / stride; // one column per active lane
 	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
 	TravCount tc; tc.pairs = 0, tc.prims = 0;
-	bool alive = false;
-	uint32_t slot = 0, flags = 0, rng = 0;
-	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), T = mk3( 0, 0, 0 );
-	if (i < n && threadIdx.x % stride == 0)
+	for (;;)
 	{
-		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
-		const uint32_t meta = in.meta[i];
-		slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w );
-		O = mk3( ot ), D = mk3( dh ), T = mk3( ts );
-		alive = true;
-		for (int nb = 0; nb < max_bounces; nb++)
-		{
-			// Scene::FindNearest from scratch (the analytic part stored with the entry is recomputed: same bits)
-			RayHit h;
-			const bool walk = begin_closest( s, O, D, h );
-			nExt++;
-			if (walk)
-			{
-				nExtWalk++;
-				const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
-				const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-				if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, 64, tc );
-				else traverse<false, false, false>( s, O, D, rD, h, stack, 64, tc );
-			}
-			Vertex v;
-			shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, E, slot, v );
-			if (v.shadow_any)
-			{
-				nSh++;
-				bool occluded, swalk;
-				begin_any( s, v.shO, v.shD, v.shT, occluded, swalk );
-				if (!occluded && !swalk)
-				{
-					float4 e = E[slot];
-					e.x += v.contrib.x, e.y += v.contrib.y, e.z += v.contrib.z;
-					E[slot] = e;
-				}
-				else if (swalk)
-				{
-					nShWalk++;
-					RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
-					const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
-					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-					const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, 64, tc ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, 64, tc );
-					if (!occ) add_shadow_contribution( Es, E, slot, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
-				}
-			}
-			if (!v.push_next) { alive = false; break; }
-			O = v.newO, D = v.newD;
-		}
-	}
-	// survivors of this round, compacted (one atomic per wave)
-	const unsigned long long m = __ballot( alive );
-	if (m)
-	{
-		const int leader = __ffsll( (long long)m ) - 1;
 		uint32_t base = 0;
-		if ((int)threadIdx.x == leader) base = atomicAdd( n_out, (uint32_t)__popcll( m ) );
-		const uint32_t j = __shfl( base, leader, 64 ) + __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) );
-		if (alive)
+		if (threadIdx.x == 0) base = atomicAdd( &ctr->pool_tail, (uint32_t)per_wave );
+		base = __shfl( base, 0, 64 );
+		if (base >= n) break; // wave-uniform
+		const uint32_t i = base + threadIdx.x / stride;
+		bool alive = false;
+		uint32_t slot = 0, flags = 0, rng = 0;
+		f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), T = mk3( 0, 0, 0 );
+		if (i < n && threadIdx.x % stride == 0)
 		{
-			out.o_t[j] = make_float4( O.x, O.y, O.z, 1e34f );
-			out.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( -1 ) );
-			out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
-			out.meta[j] = slot | ( flags << 30 );
+			const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
+			const uint32_t meta = in.meta[i];
+			slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w );
+			O = mk3( ot ), D = mk3( dh ), T = mk3( ts );
+			alive = true;
+			for (int nb = 0; nb < max_bounces; nb++)
+			{
+				// Scene::FindNearest from scratch (the analytic part stored with the entry is recomputed: same bits)
+				RayHit h;
+				const bool walk = begin_closest( s, O, D, h );
+				nExt++;
+				if (walk)
+				{
+					nExtWalk++;
+					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+					if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, per_wave, tc );
+					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
+				}
+				Vertex v;
+				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, E, slot, v );
+				if (v.shadow_any)
+				{
+					nSh++;
+					bool occluded, swalk;
+					begin_any( s, v.shO, v.shD, v.shT, occluded, swalk );
+					if (!occluded && !swalk)
+					{
+						float4 e = E[slot];
+						e.x += v.contrib.x, e.y += v.contrib.y, e.z += v.contrib.z;
+						E[slot] = e;
+					}
+					else if (swalk)
+					{
+						nShWalk++;
+						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
+						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
+						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc );
+						if (!occ) add_shadow_contribution( Es, E, slot, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
+					}
+				}
+				if (!v.push_next) { alive = false; break; }
+				O = v.newO, D = v.newD;
+			}
 		}
-	}
+		// survivors of this round, compacted (one atomic per wave)
+		const unsigned long long m = __ballot( alive );
+		if (m)
+		{
+			const int leader = __ffsll( (long long)m ) - 1;
+			uint32_t base = 0;
+			if ((int)threadIdx.x == leader) base = atomicAdd( n_out, (uint32_t)__popcll( m ) );
+			const uint32_t j = __shfl( base, leader, 64 ) + __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) );
+			if (alive)
+			{
+				out.o_t[j] = make_float4( O.x, O.y, O.z, 1e34f );
+				out.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( -1 ) );
+				out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+				out.meta[j] = slot | ( flags << 30 );
+			}
+		}
+	} // next per_wave paths
 	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
 }
@@ -707,7 +720,7 @@ __global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathStat
 // end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
 __global__ void k_next_bounce( DevCounters* ctr, int consumed )
 {
-	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_extend = 0, ctr->pool_connect = 0;
+	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_extend = 0, ctr->pool_connect = 0, ctr->pool_tail = 0;
 	ctr->n_rec[consumed ^ 1] = 0, ctr->n_srec[consumed ^ 1] = 0; // read by this bounce's walks, written again by the next bounce's
 	ctr->pending = ctr->n_state[consumed ^ 1] + ctr->n_shadow[consumed ^ 1];
 }
@@ -984,7 +997,7 @@ __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int
 // some of which live for thousands of bounces) and its k_accumulate run on the slot's own stream, so that they overlap
 // the bulk bounces of the following batches.  k_accumulate launches are chained by events in batch order (the
 // accumulator sums samples in sample order, renderer.cpp:566-567).
-#define MAX_SLOTS 8
+#define MAX_SLOTS 16
 struct BatchSlot
 {
 	int batch = 0;              // capacity in samples
@@ -1023,10 +1036,14 @@ struct rtmi_ctx
 	uint32_t* pixels = 0, *pixels2 = 0, *gamma_lut = 0;
 	// path tracing: up to MAX_SLOTS render batches in flight (see BatchSlot)
 	BatchSlot slots[MAX_SLOTS];
-	int n_slots = 6, next_slot = 0;
+	int n_slots = 4, next_slot = 0;
 	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
-	int tail_lanes = 4;          // paths per wave in the tail rounds after the first (power of two <= 64)
+	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
+	int sblock = 512;            // threads per block of k_primary / k_shade (RTMI_SBLOCK): blocks of 16 waves wait for a CU with 4 free
+	                             // slots on every SIMD, which the long-lived tail waves of earlier batches rarely leave
+	int tail_waves = 8;          // resident k_tail waves per CU
+	uint32_t tail_dense = 4096, tail_mid = 0; // k_tail: 64 paths per wave above tail_dense live paths, 16 above tail_mid, else tail_lanes
 	bool log_bounces = false;   // RTMI_LOG_BOUNCES: print the path count per bounce (diagnostics)
 	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
 	WFrame* frames = 0;
@@ -1173,9 +1190,17 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		// batches in flight: each uses its own stream, and streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES,
 		// 4 unless the process raises it before HIP starts) serialise behind each other
 		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
-		c->n_slots = ( q && atoi( q ) >= 7 ) ? 6 : 4;
+		c->n_slots = ( q && atoi( q ) >= 13 ) ? 12 : ( q && atoi( q ) >= 7 ) ? 6 : 4;
 		const char* e = getenv( "RTMI_TAIL_LANES" );
 		if (e) { const int v = atoi( e ); if (v >= 1 && v <= 64 && ( v & ( v - 1 ) ) == 0) c->tail_lanes = v; }
+		e = getenv( "RTMI_TAIL_WAVES" );
+		if (e && atoi( e ) >= 1 && atoi( e ) <= 32) c->tail_waves = atoi( e );
+		e = getenv( "RTMI_SBLOCK" );
+		if (e && ( atoi( e ) == 256 || atoi( e ) == 512 || atoi( e ) == 1024 )) c->sblock = atoi( e );
+		e = getenv( "RTMI_TAIL_DENSE" );
+		if (e && atoll( e ) >= 0) c->tail_dense = (uint32_t)atoll( e );
+		e = getenv( "RTMI_TAIL_MID" );
+		if (e && atoll( e ) >= 0) c->tail_mid = (uint32_t)atoll( e );
 		e = getenv( "RTMI_SLOTS" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= MAX_SLOTS) c->n_slots = atoi( e );
 		e = getenv( "RTMI_TAIL_PATHS" );
@@ -1465,7 +1490,7 @@ int rtmi_set_accumulator( rtmi_ctx* c, void* p )
 
 static size_t stack_bytes( rtmi_ctx* c ) { return (size_t)c->stack_depth * BLOCK * sizeof( uint32_t ); }
 
-static inline int nsblocks( size_t n ) { return (int)( ( n + SBLOCK - 1 ) / SBLOCK ); }
+static inline int nsblocks( rtmi_ctx* c, size_t n ) { return (int)( ( n + c->sblock - 1 ) / c->sblock ); }
 // persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need
 static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); }
 
@@ -1497,7 +1522,7 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
 {
 	ScopedTimer t( c, 1 );
-	hipLaunchKernelGGL( k_primary, dim3( nsblocks( N ) ), dim3( SBLOCK ), 0, c->stream, c->ds, b.st[0], b.E, (float4*)b.Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
+	hipLaunchKernelGGL( k_primary, dim3( nsblocks( c, N ) ), dim3( c->sblock ), 0, c->stream, c->ds, b.st[0], b.E, (float4*)b.Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
 		c->seeds, sample_begin, stride, b.wq[0], b.ctr );
 }
 
@@ -1529,7 +1554,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		launch_trace( c, b, false, cur, upper, budget );
 		{
 			ScopedTimer t( c, 1 );
-			hipLaunchKernelGGL( k_shade, dim3( nsblocks( upper ) ), dim3( SBLOCK ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], b.E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
+			hipLaunchKernelGGL( k_shade, dim3( nsblocks( c, upper ) ), dim3( c->sblock ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], b.E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
 				b.wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
 		launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
@@ -1553,17 +1578,20 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	hipStream_t ts = b.tail_stream;
 	HIPCHK( hipEventRecord( b.bulk_done, s ) );
 	HIPCHK( hipStreamWaitEvent( ts, b.bulk_done, 0 ) );
-	if (tail)
+	if (tail && !getenv( "RTMI_DROP_TAIL" )) // (RTMI_DROP_TAIL: timing experiment only, the image is wrong)
 	{
 		// rounds of 32, 64, 128, ... bounces, enqueued blind (a round over an empty queue returns at once); survivors are
 		// compacted between rounds; the last round has no limit
 		ScopedTimer t( c, 3, ts );
-		const size_t lds = (size_t)c->stack_depth * 64 * sizeof( uint32_t );
+		const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves );
 		for (int round = 0, len = 32; round <= 11; round++, len *= 2)
 		{
 			const int limit = round == 11 ? 0x7FFFFFFF : len;
-			const int per = round == 0 ? 64 : c->tail_lanes; // the first round is throughput work (most paths end in it)
-			hipLaunchKernelGGL( k_tail, dim3( ( upper + per - 1 ) / per ), dim3( 64 ), lds, ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, per, ctr );
+			// waves: enough for the round's upper bound at the density the kernel will choose at most (it reads the live count)
+			const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
+			const size_t lds = (size_t)c->stack_depth * 64 * sizeof( uint32_t );
+			hipLaunchKernelGGL( k_tail, dim3( waves ), dim3( 64 ), lds, ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, ctr );
 			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur );
 			cur ^= 1;
 		}
