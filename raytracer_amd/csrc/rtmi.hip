@@ -1448,11 +1448,13 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
 	{
-		// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 8 (32 waves per CU)
+		// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 4 (16 waves per CU).  The walk is bound by
+		// the memory system's random-access throughput, not by latency: measured on the 1M-triangle scene, 4 blocks per CU
+		// run the walks 8 % faster than 6 (fewer rays in flight share each XCD's 4 MiB L2), 3 as fast as 4, 2 as slow as 6.
 		const size_t per_block = (size_t)c->stack_depth * BLOCK * sizeof( uint32_t );
-		int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) );
+		int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 4, ( 160 * 1024 ) / per_block ) );
 		const char* e = getenv( "RTMI_BLOCKS_PER_CU" );
-		if (e && atoi( e ) >= 1) per_cu = std::min( per_cu, atoi( e ) );
+		if (e && atoi( e ) >= 1) per_cu = (int)std::min<size_t>( atoi( e ), std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) ) );
 		c->max_blocks = c->n_cus * per_cu;
 	}
 	return RTMI_OK;
