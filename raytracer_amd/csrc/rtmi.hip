@@ -718,11 +718,15 @@ __global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathStat
 }
 
 // end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
-__global__ void k_next_bounce( DevCounters* ctr, int consumed )
+// `report` (may be null): a word of pinned host memory that receives the number of paths + carried shadow rays the next
+// bounce starts with -- written from here instead of a 4-byte copy command per bounce (a copy kernel and its launch gap)
+__global__ void k_next_bounce( DevCounters* ctr, int consumed, uint32_t* report )
 {
 	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_extend = 0, ctr->pool_connect = 0, ctr->pool_tail = 0;
 	ctr->n_rec[consumed ^ 1] = 0, ctr->n_srec[consumed ^ 1] = 0; // read by this bounce's walks, written again by the next bounce's
-	ctr->pending = ctr->n_state[consumed ^ 1] + ctr->n_shadow[consumed ^ 1];
+	const uint32_t pending = ctr->n_state[consumed ^ 1] + ctr->n_shadow[consumed ^ 1];
+	ctr->pending = pending;
+	if (report) { *report = pending; __threadfence_system(); }
 }
 
 // ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
@@ -1010,7 +1014,8 @@ struct BatchSlot
 	uint32_t rec_cap = 0;
 	int rec_stride = 0;
 	DevCounters* ctr = 0;
-	uint32_t* host_counts = 0;  // pinned ring of read-back queue lengths
+	uint32_t* host_counts = 0;  // pinned, device-mapped ring of queue lengths written by k_next_bounce
+	uint32_t* host_counts_dev = 0; // the same ring as the device sees it
 	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
 	hipStream_t tail_stream = 0;
 	hipEvent_t bulk_done = 0, acc_done = 0;
@@ -1217,7 +1222,8 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	for (int k = 0; k < c->n_slots; k++)
 	{
 		BatchSlot& b = c->slots[k];
-		if (dev_alloc( c, &b.ctr, 1 ) || hipHostMalloc( (void**)&b.host_counts, 4 * sizeof( uint32_t ), hipHostMallocDefault ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+		if (dev_alloc( c, &b.ctr, 1 ) || hipHostMalloc( (void**)&b.host_counts, 4 * sizeof( uint32_t ), hipHostMallocMapped ) != hipSuccess ||
+			hipHostGetDevicePointer( (void**)&b.host_counts_dev, b.host_counts, 0 ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
 		// (a low-priority stream would suit the tails, but a run with hipStreamCreateWithPriority stopped making progress here)
 		bool ok = hipStreamCreateWithFlags( &b.tail_stream, hipStreamNonBlocking ) == hipSuccess;
 		for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags( &b.count_ev[i], hipEventDisableTiming ) == hipSuccess;
@@ -1560,11 +1566,11 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 				b.wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
 		launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
-		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
-		c->stats.bounce_launches++;
-		// read back what the next bounce starts with (paths + carried shadow rays); it is looked at two iterations later
+		// what the next bounce starts with (paths + carried shadow rays) goes to pinned host memory; it is looked at two
+		// iterations later
 		const int slot = bounce & 3;
-		HIPCHK( hipMemcpyAsync( &b.host_counts[slot], &ctr->pending, 4, hipMemcpyDeviceToHost, s ) );
+		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, b.host_counts_dev + slot );
+		c->stats.bounce_launches++;
 		HIPCHK( hipEventRecord( b.count_ev[slot], s ) );
 		cur ^= 1;
 		if (bounce >= 2)
@@ -1594,7 +1600,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			const size_t lds = (size_t)c->stack_depth * 64 * sizeof( uint32_t );
 			hipLaunchKernelGGL( k_tail, dim3( waves ), dim3( 64 ), lds, ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
 				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, ctr );
-			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur );
+			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 			cur ^= 1;
 		}
 		c->stats.bounce_launches++;
