@@ -621,8 +621,8 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // round holds one long path, and a thousand almost-empty resident waves would starve the next batches' bulk kernels).
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
-__global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathState out, float4* __restrict__ E, long long* __restrict__ Es, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, DevCounters* ctr )
+__global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, float4* __restrict__ E, long long* __restrict__ Es, const uint32_t* __restrict__ n_in,
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
@@ -635,20 +635,26 @@ __global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathStat
 	const uint32_t n = *n_in;
 	const int per_wave = n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
 	const uint32_t stride = 64u / (uint32_t)per_wave;
-	uint32_t* stack = lds_stack + threadIdx.x / stride; // one column per active lane
+	// Workgroups of several waves: the waves of this kernel live for milliseconds, and a CU that hosts one serves the
+	// blocks of the next batches' k_shade at about half speed (the old wave wins the issue arbitration; the block's barriers
+	// wait for its slowest wave): 250 tail waves spread one to a CU slowed every k_shade launch by 1.5-2x.  Waves that the
+	// round's live path count does not need leave at once, so the ones that stay are the first blocks of the grid: a few CUs.
+	const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+	if (( blockIdx.x * waves_per_block + wave_in_block ) * (uint32_t)per_wave >= n) return; // wave-uniform
+	uint32_t* stack = lds_stack + wave_in_block * ( lds_words / waves_per_block ) + lane / stride; // one column per active lane
 	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
 	TravCount tc; tc.pairs = 0, tc.prims = 0;
 	for (;;)
 	{
 		uint32_t base = 0;
-		if (threadIdx.x == 0) base = atomicAdd( &ctr->pool_tail, (uint32_t)per_wave );
+		if (lane == 0) base = atomicAdd( &ctr->pool_tail, (uint32_t)per_wave );
 		base = __shfl( base, 0, 64 );
 		if (base >= n) break; // wave-uniform
-		const uint32_t i = base + threadIdx.x / stride;
+		const uint32_t i = base + lane / stride;
 		bool alive = false;
 		uint32_t slot = 0, flags = 0, rng = 0;
 		f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), T = mk3( 0, 0, 0 );
-		if (i < n && threadIdx.x % stride == 0)
+		if (i < n && lane % stride == 0)
 		{
 			const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
 			const uint32_t meta = in.meta[i];
@@ -702,7 +708,7 @@ __global__ __launch_bounds__( 64 ) void k_tail( DScene s, PathState in, PathStat
 		{
 			const int leader = __ffsll( (long long)m ) - 1;
 			uint32_t base = 0;
-			if ((int)threadIdx.x == leader) base = atomicAdd( n_out, (uint32_t)__popcll( m ) );
+			if ((int)lane == leader) base = atomicAdd( n_out, (uint32_t)__popcll( m ) );
 			const uint32_t j = __shfl( base, leader, 64 ) + __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) );
 			if (alive)
 			{
@@ -1048,6 +1054,7 @@ struct rtmi_ctx
 	int sblock = 512;            // threads per block of k_primary / k_shade (RTMI_SBLOCK): blocks of 16 waves wait for a CU with 4 free
 	                             // slots on every SIMD, which the long-lived tail waves of earlier batches rarely leave
 	int tail_waves = 8;          // resident k_tail waves per CU
+	int tail_block = 4;          // waves per k_tail workgroup (RTMI_TAIL_BLOCK)
 	uint32_t tail_dense = 4096, tail_mid = 0; // k_tail: 64 paths per wave above tail_dense live paths, 16 above tail_mid, else tail_lanes
 	bool log_bounces = false;   // RTMI_LOG_BOUNCES: print the path count per bounce (diagnostics)
 	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
@@ -1202,6 +1209,8 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		if (e && atoi( e ) >= 1 && atoi( e ) <= 32) c->tail_waves = atoi( e );
 		e = getenv( "RTMI_SBLOCK" );
 		if (e && ( atoi( e ) == 256 || atoi( e ) == 512 || atoi( e ) == 1024 )) c->sblock = atoi( e );
+		e = getenv( "RTMI_TAIL_BLOCK" );
+		if (e && atoi( e ) >= 1 && atoi( e ) <= 16) c->tail_block = atoi( e );
 		e = getenv( "RTMI_TAIL_DENSE" );
 		if (e && atoll( e ) >= 0) c->tail_dense = (uint32_t)atoll( e );
 		e = getenv( "RTMI_TAIL_MID" );
@@ -1597,9 +1606,10 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			const int limit = round == 11 ? 0x7FFFFFFF : len;
 			// waves: enough for the round's upper bound at the density the kernel will choose at most (it reads the live count)
 			const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
-			const size_t lds = (size_t)c->stack_depth * 64 * sizeof( uint32_t );
-			hipLaunchKernelGGL( k_tail, dim3( waves ), dim3( 64 ), lds, ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, ctr );
+			const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->stack_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
+			const uint32_t lds_words = (uint32_t)c->stack_depth * 64u * wpb;
+			hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, ctr );
 			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 			cur ^= 1;
 		}
