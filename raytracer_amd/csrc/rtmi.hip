@@ -622,7 +622,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
 __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, float4* __restrict__ E, long long* __restrict__ Es, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
@@ -633,7 +633,10 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	// while thousands are alive (throughput), 16 and then min_lanes per wave for the last few hundred (latency).
 	// The grid is a bounded number of resident waves that pull per_wave paths at a time.
 	const uint32_t n = *n_in;
-	const int per_wave = n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
+	// `draining` (pinned host memory): the host has nothing more to enqueue and waits for the tails (rtmi_flush, read-backs):
+	// from then on a round runs for latency, 4 paths to a wave, whatever its path count (round 0 excepted)
+	const bool hurry = dense_above != 0 && *(const volatile uint32_t*)draining != 0;
+	const int per_wave = hurry ? 4 : n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
 	const uint32_t stride = 64u / (uint32_t)per_wave;
 	// Workgroups of several waves: the waves of this kernel live for milliseconds, and a CU that hosts one serves the
 	// blocks of the next batches' k_shade at about half speed (the old wave wins the issue arbitration; the block's barriers
@@ -1048,6 +1051,7 @@ struct rtmi_ctx
 	// path tracing: up to MAX_SLOTS render batches in flight (see BatchSlot)
 	BatchSlot slots[MAX_SLOTS];
 	int n_slots = 4, next_slot = 0;
+	uint32_t* draining = 0, *draining_dev = 0; // pinned, device-mapped flag read by k_tail (see there)
 	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
@@ -1164,6 +1168,7 @@ static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 // enqueued on the handle's stream after this call.
 static int join_batches( rtmi_ctx* c )
 {
+	if (c->draining) *(volatile uint32_t*)c->draining = 1; // the caller is about to wait for the tails
 	if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
 	return RTMI_OK;
 }
@@ -1228,6 +1233,8 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	if (dev_alloc( c, &c->seeds, n ) || dev_alloc( c, &c->accum_own, n ) || dev_alloc( c, &c->pixels, n ) || dev_alloc( c, &c->pixels2, n ) ||
 		dev_alloc( c, &c->gamma_lut, 256 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
 	c->accum = c->accum_own;
+	if (hipHostMalloc( (void**)&c->draining, 64, hipHostMallocMapped ) != hipSuccess || hipHostGetDevicePointer( (void**)&c->draining_dev, c->draining, 0 ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+	*c->draining = 0;
 	for (int k = 0; k < c->n_slots; k++)
 	{
 		BatchSlot& b = c->slots[k];
@@ -1267,6 +1274,7 @@ int rtmi_destroy( rtmi_ctx* c )
 		if (b.acc_done) (void)hipEventDestroy( b.acc_done );
 		if (b.tail_stream) (void)hipStreamDestroy( b.tail_stream );
 	}
+	if (c->draining) (void)hipHostFree( c->draining );
 	for (auto e : c->ev_pool) (void)hipEventDestroy( e );
 	if (c->own_stream) (void)hipStreamDestroy( c->own_stream );
 	delete c;
@@ -1609,7 +1617,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->stack_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
 			const uint32_t lds_words = (uint32_t)c->stack_depth * 64u * wpb;
 			hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, ctr );
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, ctr );
 			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 			cur ^= 1;
 		}
@@ -1653,6 +1661,7 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 	if (mode == RTMI_PATHTRACING)
 	{
 		if (sample_count <= 0 || sample_stride <= 0 || sample_begin < 0) return fail( c, RTMI_ERR_INVALID, "bad sample range" );
+		*(volatile uint32_t*)c->draining = 0; // more bulk work is coming: the tails in flight run for throughput again
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
 		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
 		const char* env = getenv( "RTMI_BATCH" );
