@@ -1603,7 +1603,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	hipStream_t ts = b.tail_stream;
 	HIPCHK( hipEventRecord( b.bulk_done, s ) );
 	HIPCHK( hipStreamWaitEvent( ts, b.bulk_done, 0 ) );
-	if (tail && !getenv( "RTMI_DROP_TAIL" )) // (RTMI_DROP_TAIL: timing experiment only, the image is wrong)
+	if (tail)
 	{
 		// rounds of 32, 64, 128, ... bounces, enqueued blind (a round over an empty queue returns at once); survivors are
 		// compacted between rounds; the last round has no limit
