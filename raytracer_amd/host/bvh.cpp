@@ -4,6 +4,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <numeric>
+#include <cstdio>
+#include <omp.h>
 
 namespace rtmi {
 
@@ -76,7 +78,9 @@ void BVH::Allocate()
 	bvhNode = (BVHNode*)aligned_alloc( 64, ( (size_t)nNodes * sizeof( BVHNode ) + 63 ) & ~(size_t)63 );
 	gpuBvhNode = (GPUBVHNode*)aligned_alloc( 64, ( (size_t)nNodes * sizeof( GPUBVHNode ) + 63 ) & ~(size_t)63 );
 	primitiveIdx = (int*)aligned_alloc( 64, ( (size_t)( n > 0 ? n : 1 ) * sizeof( int ) + 63 ) & ~(size_t)63 );
-	memset( (void*)bvhNode, 0, (size_t)nNodes * sizeof( BVHNode ) );
+#pragma omp parallel for schedule( static )
+	for (int i = 0; i < nNodes; i++) memset( (void*)( bvhNode + i ), 0, sizeof( BVHNode ) );
+#pragma omp parallel for schedule( static )
 	for (int i = 0; i < n; i++) primitiveIdx[i] = i;
 	nodesUsed = 3;
 	// node 0: dummy root; node 1: plane leaf; node 2: primitive root (bvh.h:262-271)
@@ -255,6 +259,7 @@ static void Renumber( BVH* b, const TmpNode* pool )
 void BVH::FlattenForGPU()
 {
 	const int nNodes = NodeCapacity();
+#pragma omp parallel for schedule( static )
 	for (int i = 0; i < nNodes; i++) // bvh.h:277-287
 	{
 		gpuBvhNode[i].aabbMinx = bvhNode[i].aabbMin.x, gpuBvhNode[i].aabbMiny = bvhNode[i].aabbMin.y, gpuBvhNode[i].aabbMinz = bvhNode[i].aabbMin.z;
@@ -281,65 +286,147 @@ void BVH::BuildBVH()
 // ---------------------------------------------------------------------------------------------------------
 // Binned SAH (16 bins on centroid bounds), object-median fallback.  Same node conventions; leaves hold <= 4
 // primitives unless all centroids coincide.
-static void SubdivideBinnedTmp( BuildCtx& c, int nodeIdx, int depth )
+// The builder works on an array of 40-byte records {bounds, centroid, primitive id} that is kept in node order (a
+// partition moves the records), so every pass over a node streams memory instead of gathering 116-byte Triangles
+// through primitiveIdx.  A node is processed in three passes: centroid bounds; bin boxes and counts of all three axes;
+// partition + bounds of the two children.  Nodes above BIG_NODE primitives (the top levels of a 10^6..10^7-triangle
+// tree, where there are fewer nodes than cores) run each pass as OpenMP tasks over chunks and merge the chunk results:
+// min / max / counts do not depend on the order, so the tree (split planes, boxes, primitive sets per node) is the same
+// whatever the thread count; only the order of primitives inside a leaf range can differ.
+namespace {
+const int BINS = 16;
+const int BIG_NODE = 1 << 16, CHUNK = 1 << 14;
+struct Rec { float3 mn, mx, c; int id; };
+struct AxisBins { SahBox box[3][BINS]; int cnt[3][BINS]; };
+struct BinnedCtx { Rec* rec; TmpNode* pool; float3* cb; std::atomic<int> used; }; // cb[2*node], cb[2*node+1]: centroid bounds of the node
+struct Side { SahBox box, cen; void add( const Rec& q ) { box.bmin = fminf3( box.bmin, q.mn ), box.bmax = fmaxf3( box.bmax, q.mx ), cen.grow( q.c ); } void add( const Side& o ) { box.grow( o.box ), cen.grow( o.cen ); } };
+
+inline int BinOf( float c, float lo, float scale )
 {
-	const int BINS = 16;
+	int bin = (int)( ( c - lo ) * scale );
+	return bin < 0 ? 0 : ( bin > BINS - 1 ? BINS - 1 : bin );
+}
+void CentroidBounds( const Rec* r, uint n, float3& cmn, float3& cmx )
+{
+	cmn = float3( 1e30f ), cmx = float3( -1e30f );
+	for (uint i = 0; i < n; i++) cmn = fminf3( cmn, r[i].c ), cmx = fmaxf3( cmx, r[i].c );
+}
+void FillBins( const Rec* r, uint n, const float3& cmn, const float* scale, const bool* valid, AxisBins& out )
+{
+	for (int a = 0; a < 3; a++) for (int k = 0; k < BINS; k++) out.cnt[a][k] = 0, out.box[a][k] = SahBox();
+	for (uint i = 0; i < n; i++)
+		for (int a = 0; a < 3; a++)
+		{
+			if (!valid[a]) continue;
+			const int bin = BinOf( r[i].c[a], cmn[a], scale[a] );
+			SahBox& bx = out.box[a][bin];
+			out.cnt[a][bin]++, bx.bmin = fminf3( bx.bmin, r[i].mn ), bx.bmax = fmaxf3( bx.bmax, r[i].mx ); // mn <= mx per record
+		}
+}
+void RecBounds( const Rec* r, uint n, float3& mn, float3& mx )
+{
+	mn = float3( 1e30f ), mx = float3( -1e30f );
+	for (uint i = 0; i < n; i++) mn = fminf3( mn, r[i].mn ), mx = fmaxf3( mx, r[i].mx );
+}
+
+void SubdivideBinnedTmp( BinnedCtx& c, int nodeIdx, int depth )
+{
 	TmpNode& node = c.pool[nodeIdx];
 	if (node.count <= 2) return;
-	const BVH* b = c.bvh;
-	float3 cmn( 1e30f ), cmx( -1e30f );
-	for (uint i = 0; i < node.count; i++)
+	Rec* rec = c.rec + node.first;
+	const uint n = node.count;
+	const bool big = n >= (uint)BIG_NODE;
+	const int nch = big ? (int)( ( n + CHUNK - 1 ) / CHUNK ) : 1;
+	auto lo_of = [&]( int ch ) { return (uint)( (size_t)n * ch / nch ); };
+	// centroid bounds: computed by the pass that created this node (the parent's partition, or the record pass for the root)
+	const float3 cmn = c.cb[2 * nodeIdx], cmx = c.cb[2 * nodeIdx + 1];
+	// pass 2: bins of the three axes
+	float scale[3] = { 0, 0, 0 };
+	bool valid[3];
+	for (int a = 0; a < 3; a++) { valid[a] = cmx[a] > cmn[a]; if (valid[a]) scale[a] = BINS / ( cmx[a] - cmn[a] ); }
+	AxisBins bins;
+	if (!big) FillBins( rec, n, cmn, scale, valid, bins );
+	else
 	{
-		const int prim = c.primIdx[node.first + i];
-		float3 ctr( PrimCentroid( b, prim, 0 ), PrimCentroid( b, prim, 1 ), PrimCentroid( b, prim, 2 ) );
-		cmn = fminf3( cmn, ctr ), cmx = fmaxf3( cmx, ctr );
+		std::vector<AxisBins> part( nch );
+#pragma omp taskloop default( shared ) grainsize( 1 )
+		for (int ch = 0; ch < nch; ch++) FillBins( rec + lo_of( ch ), lo_of( ch + 1 ) - lo_of( ch ), cmn, scale, valid, part[ch] );
+		for (int a = 0; a < 3; a++) for (int k = 0; k < BINS; k++) bins.cnt[a][k] = 0, bins.box[a][k] = SahBox();
+		for (int ch = 0; ch < nch; ch++) for (int a = 0; a < 3; a++) for (int k = 0; k < BINS; k++)
+			bins.cnt[a][k] += part[ch].cnt[a][k], bins.box[a][k].grow( part[ch].box[a][k] );
 	}
 	int bestAxis = -1, bestBin = 0;
 	float bestCost = 1e30f;
 	for (int axis = 0; axis < 3; axis++)
 	{
-		const float lo = cmn[axis], hi = cmx[axis];
-		if (!( hi > lo )) continue;
-		const float scale = BINS / ( hi - lo );
-		SahBox box[BINS];
-		int cnt[BINS] = { 0 };
-		for (uint i = 0; i < node.count; i++)
-		{
-			const int prim = c.primIdx[node.first + i];
-			int bin = (int)( ( PrimCentroid( b, prim, axis ) - lo ) * scale );
-			bin = bin < 0 ? 0 : ( bin > BINS - 1 ? BINS - 1 : bin );
-			cnt[bin]++, GrowPrim( b, prim, box[bin] );
-		}
+		if (!valid[axis]) continue;
+		const SahBox* box = bins.box[axis];
+		const int* cnt = bins.cnt[axis];
 		float rightArea[BINS];
 		int rightCnt[BINS];
 		SahBox acc;
-		int n = 0;
-		for (int k = BINS - 1; k > 0; k--) acc.grow( box[k] ), n += cnt[k], rightArea[k] = acc.area(), rightCnt[k] = n;
-		acc = SahBox(), n = 0;
+		int m = 0;
+		for (int k = BINS - 1; k > 0; k--) acc.grow( box[k] ), m += cnt[k], rightArea[k] = acc.area(), rightCnt[k] = m;
+		acc = SahBox(), m = 0;
 		for (int k = 1; k < BINS; k++)
 		{
-			acc.grow( box[k - 1] ), n += cnt[k - 1];
-			if (n == 0 || rightCnt[k] == 0) continue;
-			const float cost = n * acc.area() + rightCnt[k] * rightArea[k];
+			acc.grow( box[k - 1] ), m += cnt[k - 1];
+			if (m == 0 || rightCnt[k] == 0) continue;
+			const float cost = m * acc.area() + rightCnt[k] * rightArea[k];
 			if (cost < bestCost) bestCost = cost, bestAxis = axis, bestBin = k;
 		}
 	}
 	const float3 e = node.mx - node.mn;
 	const float parentCost = node.count * ( e.x * e.y + e.y * e.z + e.z * e.x );
-	int i = node.first;
+	int leftCount = 0;
+	bool haveBounds = false;
+	Side L, R;
 	if (bestAxis >= 0 && ( bestCost < parentCost || node.count > 4 ))
 	{
-		const float lo = cmn[bestAxis], scale = BINS / ( cmx[bestAxis] - lo );
-		int j = i + node.count - 1;
-		while (i <= j)
+		const float lo = cmn[bestAxis], sc = scale[bestAxis];
+		if (!big)
 		{
-			int bin = (int)( ( PrimCentroid( b, c.primIdx[i], bestAxis ) - lo ) * scale );
-			bin = bin < 0 ? 0 : ( bin > BINS - 1 ? BINS - 1 : bin );
-			if (bin < bestBin) i++; else std::swap( c.primIdx[i], c.primIdx[j--] );
+			int i = 0, j = (int)n - 1;
+			while (i <= j) // every record is classified exactly once: the children's bounds come out of the same pass
+			{
+				if (BinOf( rec[i].c[bestAxis], lo, sc ) < bestBin) L.add( rec[i] ), i++; else R.add( rec[i] ), std::swap( rec[i], rec[j--] );
+			}
+			leftCount = i, haveBounds = true;
+		}
+		else
+		{
+			// pass 3 in chunks: count, then scatter (left part in chunk order, right part behind it) with the children's bounds
+			std::vector<uint> nl( nch + 1, 0 );
+#pragma omp taskloop default( shared ) grainsize( 1 )
+			for (int ch = 0; ch < nch; ch++)
+			{
+				uint k = 0;
+				for (uint i = lo_of( ch ); i < lo_of( ch + 1 ); i++) k += BinOf( rec[i].c[bestAxis], lo, sc ) < bestBin;
+				nl[ch + 1] = k;
+			}
+			for (int ch = 0; ch < nch; ch++) nl[ch + 1] += nl[ch];
+			leftCount = (int)nl[nch];
+			Rec* tmp = (Rec*)malloc( (size_t)n * sizeof( Rec ) );
+			std::vector<Side> lb( nch ), rb( nch );
+#pragma omp taskloop default( shared ) grainsize( 1 )
+			for (int ch = 0; ch < nch; ch++)
+			{
+				uint l = nl[ch], r = (uint)leftCount + ( lo_of( ch ) - nl[ch] );
+				for (uint i = lo_of( ch ); i < lo_of( ch + 1 ); i++)
+				{
+					const Rec& q = rec[i];
+					if (BinOf( q.c[bestAxis], lo, sc ) < bestBin) tmp[l++] = q, lb[ch].add( q );
+					else tmp[r++] = q, rb[ch].add( q );
+				}
+			}
+#pragma omp taskloop default( shared ) grainsize( 1 )
+			for (int ch = 0; ch < nch; ch++) memcpy( (void*)( rec + lo_of( ch ) ), (const void*)( tmp + lo_of( ch ) ), ( lo_of( ch + 1 ) - lo_of( ch ) ) * sizeof( Rec ) );
+			free( tmp );
+			for (int ch = 0; ch < nch; ch++) L.add( lb[ch] ), R.add( rb[ch] );
+			haveBounds = true;
 		}
 	}
 	else if (node.count <= 4) return;
-	int leftCount = i - node.first;
 	if (leftCount == 0 || leftCount == (int)node.count)
 	{
 		if (node.count <= 4) return;
@@ -348,19 +435,23 @@ static void SubdivideBinnedTmp( BuildCtx& c, int nodeIdx, int depth )
 		const float3 ce = cmx - cmn;
 		if (ce.y > ce.x) axis = 1;
 		if (ce.z > ce[axis]) axis = 2;
-		int* f = c.primIdx + node.first;
 		leftCount = node.count / 2;
-		std::nth_element( f, f + leftCount, f + node.count, [&]( int a, int d ) {
-			const float ka = PrimCentroid( b, a, axis ), kd = PrimCentroid( b, d, axis );
-			return ka < kd || ( ka == kd && a < d ); } );
-		i = node.first + leftCount;
+		std::nth_element( rec, rec + leftCount, rec + n, [&]( const Rec& a, const Rec& d ) {
+			return a.c[axis] < d.c[axis] || ( a.c[axis] == d.c[axis] && a.id < d.id ); } );
+		haveBounds = false;
 	}
 	const int l = c.used.fetch_add( 2 ), r = l + 1;
-	c.pool[l].first = node.first, c.pool[l].count = leftCount;
-	c.pool[r].first = i, c.pool[r].count = node.count - leftCount;
+	c.pool[l].first = node.first, c.pool[l].count = leftCount, c.pool[l].left = -1;
+	c.pool[r].first = node.first + leftCount, c.pool[r].count = node.count - leftCount, c.pool[r].left = -1;
 	node.left = l;
-	RangeBounds( b, c.primIdx, c.pool[l].first, c.pool[l].count, c.pool[l].mn, c.pool[l].mx );
-	RangeBounds( b, c.primIdx, c.pool[r].first, c.pool[r].count, c.pool[r].mn, c.pool[r].mx );
+	if (!haveBounds)
+	{
+		L = Side(), R = Side();
+		for (int i = 0; i < leftCount; i++) L.add( rec[i] );
+		for (uint i = (uint)leftCount; i < n; i++) R.add( rec[i] );
+	}
+	c.pool[l].mn = L.box.bmin, c.pool[l].mx = L.box.bmax, c.pool[r].mn = R.box.bmin, c.pool[r].mx = R.box.bmax;
+	c.cb[2 * l] = L.cen.bmin, c.cb[2 * l + 1] = L.cen.bmax, c.cb[2 * r] = R.cen.bmin, c.cb[2 * r + 1] = R.cen.bmax;
 	if (node.count >= (uint)PAR_THRESHOLD)
 	{
 #pragma omp task shared( c ) firstprivate( l, depth )
@@ -371,20 +462,53 @@ static void SubdivideBinnedTmp( BuildCtx& c, int nodeIdx, int depth )
 	}
 	else SubdivideBinnedTmp( c, l, depth + 1 ), SubdivideBinnedTmp( c, r, depth + 1 );
 }
+} // namespace
 
 void BVH::BuildBVHBinned()
 {
+	const bool timing = getenv( "RTMI_BUILD_TIMING" ) != 0;
+	double t0 = omp_get_wtime(), t1;
+	auto lap = [&]( const char* what ) { t1 = omp_get_wtime(); if (timing) fprintf( stderr, "rtmi build: %-10s %.3f s\n", what, t1 - t0 ); t0 = t1; };
 	Allocate();
+	lap( "allocate" );
 	const int n = spheres_size + triangles_size;
-	std::vector<TmpNode> pool( (size_t)n * 2 + 2 );
-	BuildCtx c{ this, primitiveIdx, pool.data(), { 1 } };
-	pool[0].first = 0, pool[0].count = n;
-	RangeBounds( this, primitiveIdx, 0, n, pool[0].mn, pool[0].mx );
+	// untouched memory: a node's fields are written when the node is created
+	TmpNode* pool = (TmpNode*)malloc( ( (size_t)n * 2 + 2 ) * sizeof( TmpNode ) );
+	Rec* rec = (Rec*)malloc( (size_t)( n > 0 ? n : 1 ) * sizeof( Rec ) );
+	const int nch = std::max( 1, n / CHUNK );
+	std::vector<float3> mn( nch ), mx( nch ), cn( nch ), cx( nch );
+	float3* cb = (float3*)malloc( ( (size_t)n * 2 + 2 ) * 2 * sizeof( float3 ) );
+#pragma omp parallel for schedule( dynamic, 1 )
+	for (int ch = 0; ch < nch; ch++)
+	{
+		const int lo = (int)( (size_t)n * ch / nch ), hi = (int)( (size_t)n * ( ch + 1 ) / nch );
+		for (int i = lo; i < hi; i++)
+		{
+			Rec& q = rec[i];
+			PrimBounds( i, q.mn, q.mx );
+			q.c = float3( PrimCentroid( this, i, 0 ), PrimCentroid( this, i, 1 ), PrimCentroid( this, i, 2 ) ), q.id = i;
+		}
+		RecBounds( rec + lo, (uint)( hi - lo ), mn[ch], mx[ch] );
+		CentroidBounds( rec + lo, (uint)( hi - lo ), cn[ch], cx[ch] );
+	}
+	pool[0].first = 0, pool[0].count = n, pool[0].left = -1;
+	pool[0].mn = float3( 1e30f ), pool[0].mx = float3( -1e30f );
+	cb[0] = float3( 1e30f ), cb[1] = float3( -1e30f );
+	for (int ch = 0; ch < nch; ch++) pool[0].mn = fminf3( pool[0].mn, mn[ch] ), pool[0].mx = fmaxf3( pool[0].mx, mx[ch] ), cb[0] = fminf3( cb[0], cn[ch] ), cb[1] = fmaxf3( cb[1], cx[ch] );
+	lap( "records" );
+	BinnedCtx c{ rec, pool, cb, { 1 } };
 #pragma omp parallel
 #pragma omp single
 	SubdivideBinnedTmp( c, 0, 0 );
-	Renumber( this, pool.data() );
+	lap( "subdivide" );
+#pragma omp parallel for schedule( static )
+	for (int i = 0; i < n; i++) primitiveIdx[i] = rec[i].id;
+	free( rec ), free( cb );
+	Renumber( this, pool );
+	free( pool );
+	lap( "renumber" );
 	FlattenForGPU();
+	lap( "flatten" );
 }
 
 } // namespace rtmi

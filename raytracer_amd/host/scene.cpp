@@ -25,9 +25,14 @@ void Scene::AddCube( float3 pos, float3 size, const Material& m, const mat4& T )
 void Scene::AddPlane( float3 N, float d, const Material& m ) { vp.push_back( Plane( 0, N, d, m ) ); }
 void Scene::AddTriangles( const float* v, size_t count, const Material& m, float3 off )
 {
-	vt.reserve( vt.size() + count );
-	for (size_t i = 0; i < count; i++, v += 9)
-		vt.push_back( Triangle( 0, float3( v[0], v[1], v[2] ) + off, float3( v[3], v[4], v[5] ) + off, float3( v[6], v[7], v[8] ) + off, m ) );
+	const size_t base = vt.size();
+	vt.resize( base + count );
+#pragma omp parallel for schedule( static )
+	for (long long i = 0; i < (long long)count; i++)
+	{
+		const float* q = v + 9 * i;
+		vt[base + i] = Triangle( 0, float3( q[0], q[1], q[2] ) + off, float3( q[3], q[4], q[5] ) + off, float3( q[6], q[7], q[8] ) + off, m );
+	}
 }
 
 // scale 1 is the reference room.  The reference's triangle test rejects |det| < 1e-4 (primitive.h:59), i.e. every
@@ -183,7 +188,12 @@ void Scene::Finalize( BVH::Builder builder )
 	for (auto& s : vs) s.objIdx = id++;
 	for (auto& c : vc) c.objIdx = id++;
 	for (auto& p : vp) p.objIdx = id++;
-	for (auto& t : vt) t.objIdx = id++;
+	{
+		const int first = id;
+#pragma omp parallel for schedule( static )
+		for (long long k = 0; k < (long long)vt.size(); k++) vt[k].objIdx = first + (int)k;
+		id += (int)vt.size();
+	}
 	delete bvh;
 	bvh = new BVH( spheres, spheres_size, planes, planes_size, triangles, triangles_size, builder );
 
@@ -207,11 +217,13 @@ void Scene::Finalize( BVH::Builder builder )
 		cubeBs[2 * k] = float4( cubes[k].b[0], 0 ), cubeBs[2 * k + 1] = float4( cubes[k].b[1], 0 ), primitives[i] = float4( 0 );
 	for (int k = 0; k < planes_size; k++, i++) // scene.h:165-171
 		mat( i, planes[k].material ), primitives[i] = float4( planes[k].N, planes[k].d );
-	for (int k = 0; k < triangles_size; k++, i++) // scene.h:176-185
+	const int triBase = i;
+#pragma omp parallel for schedule( static )
+	for (int k = 0; k < triangles_size; k++) // scene.h:176-185
 	{
-		mat( i, triangles[k].material );
+		mat( triBase + k, triangles[k].material );
 		triangleInfos[3 * (size_t)k] = float4( triangles[k].pos1, 0.0f ), triangleInfos[3 * (size_t)k + 1] = float4( triangles[k].pos2, 0.0f );
-		triangleInfos[3 * (size_t)k + 2] = float4( triangles[k].pos3, 0.0f ), primitives[i] = float4( triangles[k].N, 0 );
+		triangleInfos[3 * (size_t)k + 2] = float4( triangles[k].pos3, 0.0f ), primitives[triBase + k] = float4( triangles[k].N, 0 );
 	}
 
 	desc = rtmi_scene_desc{};
