@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--builder", choices=["binned", "reference"], default="binned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
                     help="HBM bytes per k_trace<closest> launch; default: the committed result of the separate rocprofv3 --pmc "
                          "passes (profiles/r01_traffic.json, tools/profile_gpu.sh + tools/traffic.py), null if absent")
