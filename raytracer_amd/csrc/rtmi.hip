@@ -38,7 +38,7 @@ struct PathState
 	float4* o_t;    // ray origin, hit distance
 	float4* d_h;    // ray direction, hit object index (int bits)
 	float4* T_s;    // throughput, rng state (uint bits)
-	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel) | META_SUSPENDED | flags << 30
+	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel, 25 bits) | age << 25 (4 bits) | META_SUSPENDED | flags << 30
 };
 struct ShadowQueue // only the shadow rays that have to walk the BVH
 {
@@ -66,7 +66,10 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 
 #define FLAG_SPECULAR 1u
 #define FLAG_INSIDE 2u
-#define META_SLOT_MASK 0x1FFFFFFFu
+#define META_SLOT_MASK 0x01FFFFFFu  // a batch holds at most 2^25 paths
+#define META_AGE_SHIFT 25           // vertices behind the path, saturating at META_AGE_LATE
+#define META_AGE_LATE 15u
+#define SQ_LATE 0x40000000u         // shadow queue slot word: the shadow ray left a late vertex
 #define META_SUSPENDED 0x20000000u // the closest-hit walk of this path was parked (k_trace); k_shade passes it through
 #define RESUME_BIT 0x80000000u     // walk queue entry / shadow slot field: resume from a suspend record
 #define REC_HEADER 6               // suspend record: cur, sp, k, h.obj, h.pos, -, then the stack
@@ -201,6 +204,43 @@ __device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* 
 	else atomicAdd( &E[slot].x, c.x ), atomicAdd( &E[slot].y, c.y ), atomicAdd( &E[slot].z, c.z );
 }
 
+// Where a path's radiance goes.  Up to its 15th vertex a path adds into its own slot: E[slot] is the float chain of
+// Renderer::Sample for that sample (light hits, shadow rays that needed no walk), Es[slot] the exact sum of its walked
+// shadow rays; k_accumulate adds both to the pixel in sample order.  From the 15th vertex on (a LATE vertex: the age is
+// a property of the path, not of the launch that happens to process it) every contribution goes to late[pixel], an exact
+// 64-bit fixed-point sum per pixel that is folded into the accumulator when the caller next reads it.  A late path owes
+// its batch nothing any more, so the batch's slot can be accumulated and reused while the path is still bouncing -- in
+// the queues of the following batches (k_carry_out / k_carry_in), at wavefront efficiency, instead of in a tail of its own.
+struct Sinks { float4* E; long long* Es; long long* late; float4* acc; uint32_t WH; };
+__device__ __forceinline__ void add_late( const Sinks& k, uint32_t slot, f3 c )
+{
+	const uint32_t p = slot % k.WH;
+	const bool finite = fabsf( c.x ) < 4194304.0f && fabsf( c.y ) < 4194304.0f && fabsf( c.z ) < 4194304.0f; // false for NaN
+	if (finite)
+	{
+		unsigned long long* q = (unsigned long long*)( k.late + 4 * (size_t)p );
+		const long long x = (long long)( c.x * ES_SCALE ), y = (long long)( c.y * ES_SCALE ), z = (long long)( c.z * ES_SCALE );
+		if (x) atomicAdd( q, (unsigned long long)x );
+		if (y) atomicAdd( q + 1, (unsigned long long)y );
+		if (z) atomicAdd( q + 2, (unsigned long long)z );
+	}
+	else atomicAdd( &k.acc[p].x, c.x ), atomicAdd( &k.acc[p].y, c.y ), atomicAdd( &k.acc[p].z, c.z ); // stays visible
+}
+// a contribution of the float chain (light hit, unoccluded shadow ray without a walk)
+__device__ __forceinline__ void add_chain( const Sinks& k, uint32_t slot, bool late, f3 c )
+{
+	if (late) { add_late( k, slot, c ); return; }
+	float4 e = k.E[slot];
+	e.x = e.x + c.x, e.y = e.y + c.y, e.z = e.z + c.z;
+	k.E[slot] = e;
+}
+// a walked shadow ray's contribution
+__device__ __forceinline__ void add_walked( const Sinks& k, uint32_t slot, bool late, float4 c )
+{
+	if (late) add_late( k, slot, mk3( c ) );
+	else add_shadow_contribution( k.Es, k.E, slot, c );
+}
+
 // Tail control: a launch lasts as long as its longest ray, and a few rays of this scene walk > 1500 steps against a
 // mean of 90, so from the third bounce on most of a launch was one wave finishing one ray.  Once a wave has no new
 // rays to fetch, a CLOSEST-HIT ray that is still walking `budget` steps later is SUSPENDED: its traversal state (node,
@@ -213,8 +253,7 @@ struct TraceArgs
 {
 	PathState st;            // closest: the rays' state set
 	ShadowQueue sq, sq_out;  // any: this bounce's queue; the next bounce's queue (receives the parked shadow rays)
-	long long* Es;           // any: fixed-point sum of the contributions of walked shadow rays, 4 x int64 per slot
-	float4* E;
+	Sinks sinks;             // any: where the contributions of unoccluded shadow rays go
 	const uint32_t* wq;      // closest: walk queue (entry | RESUME_BIT)
 	const uint32_t* count_ptr;
 	const uint32_t* rays_ptr;
@@ -260,7 +299,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 			{
 				if (ANY)
 				{
-					if (!occluded) add_shadow_contribution( a.Es, a.E, slot, a.sq.c[entry] ); // E += T * (...) * BRDF * emission
+					if (!occluded) add_walked( a.sinks, slot & META_SLOT_MASK, ( slot & SQ_LATE ) != 0, a.sq.c[entry] ); // E += T * (...) * BRDF * emission
 				}
 				else if (h.pos >= 0 || resumed) // a BVH primitive beat the analytic hit (a resumed ray's fields held its record)
 				{
@@ -425,7 +464,7 @@ struct Vertex
 	f3 newO, newD, shO, shD, contrib;
 	float shT;
 };
-__device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float t, int obj, f3& T, uint32_t& rng, uint32_t& flags, float4* __restrict__ E, uint32_t slot, Vertex& v )
+__device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float t, int obj, f3& T, uint32_t& rng, uint32_t& flags, const Sinks& sinks, uint32_t slot, bool late, Vertex& v )
 {
 	v.push_next = false, v.shadow_any = false, v.shT = 0;
 	if (obj == -1) return; // miss: the path ends, Sample returns E (renderer.cpp:254, 363)
@@ -438,10 +477,7 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 	{
 		if (flags & FLAG_SPECULAR) // renderer.cpp:262-263: E + T * emission
 		{
-			const f3 add = T * mk3( s.light_emission );
-			float4 e = E[slot];
-			e.x = e.x + add.x, e.y = e.y + add.y, e.z = e.z + add.z;
-			E[slot] = e;
+			add_chain( sinks, slot, late, T * mk3( s.light_emission ) );
 		}
 		return;
 	}
@@ -540,7 +576,7 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 // intersections and root box tests run here, so that a bounce is
 //   k_trace<closest>  ->  k_shade  ->  k_trace<any>
 // and rays that never reach the BVH cost no queue traffic at all. ------------------------------------------------------
-__global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, float4* __restrict__ E, const uint32_t* __restrict__ n_in,
+__global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, uint32_t* __restrict__ wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {
 	__shared__ uint32_t lds[3 * 16 + 1];
@@ -549,7 +585,8 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n = *n_in;
 	bool walk_next = false, push_shadow = false, parked = false;
-	uint32_t slot = 0, flags = 0, rng = 0;
+	uint32_t slot = 0, flags = 0, rng = 0, age = 0;
+	bool late = false;
 	f3 T;
 	Vertex v; v.push_next = false, v.shadow_any = false, v.shT = 0;
 	RayHit nh; nh.t = 1e34f, nh.obj = -1, nh.pos = -1;
@@ -558,6 +595,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
 		const uint32_t meta = in.meta[i];
 		slot = meta & META_SLOT_MASK, flags = meta >> 30, parked = ( meta & META_SUSPENDED ) != 0;
+		age = ( meta >> META_AGE_SHIFT ) & META_AGE_LATE, late = age == META_AGE_LATE;
 		const f3 O = mk3( ot ), D = mk3( dh );
 		const float t = ot.w;
 		const int obj = __float_as_int( dh.w );
@@ -570,19 +608,15 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 		}
 		else
 		{
-			shade_vertex( s, O, D, t, obj, T, rng, flags, E, slot, v );
+			shade_vertex( s, O, D, t, obj, T, rng, flags, sinks, slot, late, v );
+			age = age < META_AGE_LATE ? age + 1 : age; // the next vertex of this path
 			// the rays created here start their life here: everything of FindNearest / IsOccluded before the BVH walk
 			if (v.push_next) walk_next = begin_closest( s, v.newO, v.newD, nh );
 			if (v.shadow_any)
 			{
 				bool occluded;
 				begin_any( s, v.shO, v.shD, v.shT, occluded, push_shadow );
-				if (!occluded && !push_shadow) // unoccluded without a walk: E += contribution now (renderer.cpp:343)
-				{
-					float4 e = E[slot];
-					e.x += v.contrib.x, e.y += v.contrib.y, e.z += v.contrib.z;
-					E[slot] = e;
-				}
+				if (!occluded && !push_shadow) add_chain( sinks, slot, late, v.contrib ); // unoccluded without a walk: E += contribution now (renderer.cpp:343)
 			}
 		}
 	}
@@ -600,14 +634,14 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 		out.o_t[j] = make_float4( v.newO.x, v.newO.y, v.newO.z, nh.t );
 		out.d_h[j] = make_float4( v.newD.x, v.newD.y, v.newD.z, __int_as_float( nh.obj ) );
 		out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
-		out.meta[j] = slot | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u );
+		out.meta[j] = slot | ( age << META_AGE_SHIFT ) | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u );
 		if (walk_next) wq_out[idx[1]] = j | ( parked ? RESUME_BIT : 0u );
 	}
 	if (push_shadow)
 	{
 		const uint32_t si = idx[2];
 		sq.o_t[si] = make_float4( v.shO.x, v.shO.y, v.shO.z, v.shT );
-		sq.d_s[si] = make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot ) );
+		sq.d_s[si] = make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot | ( late ? SQ_LATE : 0u ) ) );
 		sq.c[si] = make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 );
 	}
 	if (threadIdx.x == 0 && lds[48]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[48] );
@@ -621,7 +655,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // round holds one long path, and a thousand almost-empty resident waves would starve the next batches' bulk kernels).
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
-__global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, float4* __restrict__ E, long long* __restrict__ Es, const uint32_t* __restrict__ n_in,
+__global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
@@ -634,8 +668,8 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	// The grid is a bounded number of resident waves that pull per_wave paths at a time.
 	const uint32_t n = *n_in;
 	// `draining` (pinned host memory): the host has nothing more to enqueue and waits for the tails (rtmi_flush, read-backs):
-	// from then on a round runs for latency, 4 paths to a wave, whatever its path count (round 0 excepted)
-	const bool hurry = dense_above != 0 && *(const volatile uint32_t*)draining != 0;
+	// from then on a round with no more than 4 * dense_above paths runs for latency, 4 paths to a wave (round 0 excepted)
+	const bool hurry = dense_above != 0 && n <= 4 * dense_above && *(const volatile uint32_t*)draining != 0;
 	const int per_wave = hurry ? 4 : n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
 	const uint32_t stride = 64u / (uint32_t)per_wave;
 	// Workgroups of several waves: the waves of this kernel live for milliseconds, and a CU that hosts one serves the
@@ -655,13 +689,13 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 		if (base >= n) break; // wave-uniform
 		const uint32_t i = base + lane / stride;
 		bool alive = false;
-		uint32_t slot = 0, flags = 0, rng = 0;
+		uint32_t slot = 0, flags = 0, rng = 0, age = 0;
 		f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), T = mk3( 0, 0, 0 );
 		if (i < n && lane % stride == 0)
 		{
 			const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
 			const uint32_t meta = in.meta[i];
-			slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w );
+			slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w ), age = ( meta >> META_AGE_SHIFT ) & META_AGE_LATE;
 			O = mk3( ot ), D = mk3( dh ), T = mk3( ts );
 			alive = true;
 			for (int nb = 0; nb < max_bounces; nb++)
@@ -679,18 +713,15 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
 				}
 				Vertex v;
-				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, E, slot, v );
+				const bool late = age == META_AGE_LATE;
+				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v );
+				age = age < META_AGE_LATE ? age + 1 : age;
 				if (v.shadow_any)
 				{
 					nSh++;
 					bool occluded, swalk;
 					begin_any( s, v.shO, v.shD, v.shT, occluded, swalk );
-					if (!occluded && !swalk)
-					{
-						float4 e = E[slot];
-						e.x += v.contrib.x, e.y += v.contrib.y, e.z += v.contrib.z;
-						E[slot] = e;
-					}
+					if (!occluded && !swalk) add_chain( sinks, slot, late, v.contrib );
 					else if (swalk)
 					{
 						nShWalk++;
@@ -698,7 +729,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc );
-						if (!occ) add_shadow_contribution( Es, E, slot, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
+						if (!occ) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
 				}
 				if (!v.push_next) { alive = false; break; }
@@ -718,12 +749,85 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 				out.o_t[j] = make_float4( O.x, O.y, O.z, 1e34f );
 				out.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( -1 ) );
 				out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
-				out.meta[j] = slot | ( flags << 30 );
+				out.meta[j] = slot | ( age << META_AGE_SHIFT ) | ( flags << 30 );
 			}
 		}
 	} // next per_wave paths
 	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
+}
+
+// ---- carry: the late paths (Sinks) that are alive when a batch leaves the wavefront loop join the NEXT batch's queue ------
+// k_carry_out splits the batch's last state set: late paths go to the carry buffer (while it has room), the others stay
+// with the batch (its k_tail finishes them before its k_accumulate).  k_carry_in appends the carry buffer to the state
+// queue that k_primary has just filled, as entries N, N+1, ...: camera-ray paths and carried paths then bounce together.
+// A carried path keeps its slot (it needs it for its pixel only) and its rng state: its arithmetic is what it would have
+// been in a tail of its own.
+__global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32_t* __restrict__ n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap )
+{
+	__shared__ uint32_t lds_a[16], lds_b[16];
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = *n_in;
+	float4 ot = make_float4( 0, 0, 0, 0 ), dh = ot, ts = ot;
+	uint32_t meta = 0;
+	const bool valid = i < n;
+	if (valid) ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i], meta = in.meta[i];
+	const bool late = valid && ( ( meta >> META_AGE_SHIFT ) & META_AGE_LATE ) == META_AGE_LATE && !( meta & META_SUSPENDED );
+	uint32_t idx[1];
+	{
+		const bool push[1] = { late };
+		uint32_t* const counters[1] = { n_carry };
+		block_append<1>( push, counters, idx, lds_a );
+	}
+	const bool carried = late && idx[0] < cap; // the counter may run past cap: readers clamp
+	if (carried) carry.o_t[idx[0]] = ot, carry.d_h[idx[0]] = dh, carry.T_s[idx[0]] = ts, carry.meta[idx[0]] = meta;
+	{
+		const bool push[1] = { valid && !carried };
+		uint32_t* const counters[1] = { n_rest };
+		block_append<1>( push, counters, idx, lds_b );
+	}
+	if (valid && !carried) rest.o_t[idx[0]] = ot, rest.d_h[idx[0]] = dh, rest.T_s[idx[0]] = ts, rest.meta[idx[0]] = meta;
+}
+__global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, const uint32_t* __restrict__ n_carry, uint32_t cap, PathState st, const uint32_t* __restrict__ n_st, uint32_t* __restrict__ wq, DevCounters* ctr )
+{
+	__shared__ uint32_t lds[16];
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t nc = *n_carry < cap ? *n_carry : cap, N = *n_st; // N changes only in k_carry_commit
+	bool walk = false;
+	if (j < nc)
+	{
+		const float4 ot = carry.o_t[j], dh = carry.d_h[j];
+		const f3 O = mk3( ot ), D = mk3( dh );
+		RayHit h;
+		walk = begin_closest( s, O, D, h ); // the entry's ray has not been traced yet
+		st.o_t[N + j] = make_float4( O.x, O.y, O.z, h.t );
+		st.d_h[N + j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+		st.T_s[N + j] = carry.T_s[j];
+		st.meta[N + j] = carry.meta[j];
+	}
+	const bool push[1] = { walk };
+	uint32_t* const counters[1] = { &ctr->n_walk[0] };
+	uint32_t idx[1];
+	block_append<1>( push, counters, idx, lds );
+	if (walk) wq[idx[0]] = N + j;
+}
+__global__ void k_carry_commit( uint32_t* n_st, uint32_t* n_carry, uint32_t cap )
+{
+	*n_st += *n_carry < cap ? *n_carry : cap;
+	*n_carry = 0;
+}
+// accumulator[p] += the exact sum of the late contributions of pixel p, which starts again at zero
+__global__ __launch_bounds__( BLOCK ) void k_fold_late( float4* __restrict__ acc, long long* __restrict__ late, int WH )
+{
+	const int p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= WH) return;
+	const longlong2 s01 = *(const longlong2*)( late + 4 * (size_t)p );
+	const long long s2 = late[4 * (size_t)p + 2];
+	if (( s01.x | s01.y | s2 ) == 0) return;
+	const float inv = 1.0f / ES_SCALE;
+	float4 a = acc[p];
+	a.x += (float)s01.x * inv, a.y += (float)s01.y * inv, a.z += (float)s2 * inv;
+	acc[p] = a;
+	late[4 * (size_t)p] = 0, late[4 * (size_t)p + 1] = 0, late[4 * (size_t)p + 2] = 0;
 }
 
 // end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
@@ -1027,6 +1131,8 @@ struct BatchSlot
 	uint32_t* host_counts_dev = 0; // the same ring as the device sees it
 	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
 	hipStream_t tail_stream = 0;
+	PathState left = {};        // late paths that outlived the first round of this batch's k_tail: they join the next batch that uses the slot
+	uint32_t* n_left = 0;
 	hipEvent_t bulk_done = 0, acc_done = 0;
 	bool busy = false;          // acc_done has been recorded and not yet waited for by a new user of the slot
 };
@@ -1052,6 +1158,15 @@ struct rtmi_ctx
 	BatchSlot slots[MAX_SLOTS];
 	int n_slots = 4, next_slot = 0;
 	uint32_t* draining = 0, *draining_dev = 0; // pinned, device-mapped flag read by k_tail (see there)
+	// late paths (Sinks): exact per-pixel sums, and the buffer in which the late survivors of a batch wait for the next one
+	long long* late = 0;         // 4 x int64 per pixel
+	PathState carry[2] = {};     // [0] collects (k_carry_out) and feeds (k_carry_in); [1] is the ping-pong partner of the final tail
+	DevCounters* carry_ctr = 0;  // n_state[0] = paths in carry[0]
+	uint32_t carry_cap = 1u << 22, left_cap = 1u << 16;
+	bool carry_on = true;        // RTMI_CARRY=0: every batch finishes all of its paths in its own tail
+	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
+	uint32_t small_paths = 1u << 18; // a batch with no more paths than this leaves the wavefront loop at once
+	int carry_bounce = 17;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
 	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
@@ -1151,7 +1266,7 @@ static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 	if (b.batch >= S) return RTMI_OK;
 	if (b.busy) { (void)hipEventSynchronize( b.acc_done ); b.busy = false; }
 	free_batch( b );
-	const size_t n = (size_t)S * c->W * c->H;
+	const size_t n0 = (size_t)S * c->W * c->H, n = n0 + c->carry_cap + (size_t)MAX_SLOTS * c->left_cap; // the queues also hold the paths carried in from earlier batches
 	const size_t cap = n / 8 + 1024;
 	b.rec_stride = c->stack_depth + REC_HEADER;
 	int r = RTMI_OK;
@@ -1159,16 +1274,60 @@ static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 		( r = dev_alloc( c, &b.st[k].o_t, n ) ) || ( r = dev_alloc( c, &b.st[k].d_h, n ) ) || ( r = dev_alloc( c, &b.st[k].T_s, n ) ) || ( r = dev_alloc( c, &b.st[k].meta, n ) ) ||
 			( r = dev_alloc( c, &b.wq[k], n ) ) || ( r = dev_alloc( c, &b.sq[k].o_t, n + cap ) ) || ( r = dev_alloc( c, &b.sq[k].d_s, n + cap ) ) || ( r = dev_alloc( c, &b.sq[k].c, n + cap ) ) ||
 			( r = dev_alloc( c, &b.rec[k], cap * b.rec_stride ) ) || ( r = dev_alloc( c, &b.srec[k], cap * b.rec_stride ) );
-	if (!r) ( r = dev_alloc( c, &b.E, n ) ) || ( r = dev_alloc( c, &b.Es, 4 * n ) );
+	if (!r) ( r = dev_alloc( c, &b.E, n0 ) ) || ( r = dev_alloc( c, &b.Es, 4 * n0 ) );
 	if (r) { free_batch( b ); return r; }
 	b.batch = S, b.rec_cap = (uint32_t)cap;
 	return RTMI_OK;
 }
 // Everything enqueued by earlier rtmi_render calls (tails and accumulates on the slot streams) happens-before what is
 // enqueued on the handle's stream after this call.
+static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E, k.Es = b.Es, k.late = c->late, k.acc = c->accum, k.WH = (uint32_t)( c->W * c->H ); return k; }
+
+// k_tail rounds of 32, 64, 128, ... bounces over the state set st[cur] (length ctr->n_state[cur], at most `upper`), enqueued
+// blind on `ts` (a round over an empty queue returns at once); survivors are compacted between rounds, the last round has no
+// limit.  An even number of rounds: the set that was current at the start is current, and empty, at the end.
+static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int cur, DevCounters* ctr, const Sinks& sinks, uint32_t upper, int first_round = 0, int last_round = 11 )
+{
+	const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves );
+	for (int round = first_round, len = 32 << first_round; round <= last_round; round++, len *= 2)
+	{
+		const int limit = round == 11 ? 0x7FFFFFFF : len;
+		// waves: enough for the round's upper bound at the density the kernel will choose at most (it reads the live count)
+		const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
+		const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->stack_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
+		const uint32_t lds_words = (uint32_t)c->stack_depth * 64u * wpb;
+		hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+			round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, ctr );
+		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
+		cur ^= 1;
+	}
+	return cur;
+}
+
+static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride );
+
 static int join_batches( rtmi_ctx* c )
 {
 	if (c->draining) *(volatile uint32_t*)c->draining = 1; // the caller is about to wait for the tails
+	if (c->carry_pending && c->has_scene && c->slots[c->next_slot].E)
+	{
+		// The late paths that the last batch handed on have no batch to ride with: they get a batch of their own, without
+		// camera rays (S = 0): wavefront bounces while they are many, then k_tail.
+		if (c->carry_on)
+		{
+			BatchSlot& b = c->slots[c->next_slot];
+			c->next_slot = ( c->next_slot + 1 ) % c->n_slots;
+			int r = render_batch( c, b, 0, 0, 1 );
+			if (r) return r;
+		}
+		if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
+		// fold the late sums of all batches since the last read into the accumulator
+		ScopedTimer t( c, 3 );
+		hipLaunchKernelGGL( k_fold_late, dim3( nblocks( (size_t)c->W * c->H ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->late, c->W * c->H );
+		HIPCHK( hipGetLastError() );
+		c->carry_pending = false;
+		return RTMI_OK;
+	}
 	if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
 	return RTMI_OK;
 }
@@ -1189,7 +1348,7 @@ const char* rtmi_last_error( rtmi_ctx* c ) { return c ? c->err.c_str() : "null c
 
 int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 {
-	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << 28 )) return RTMI_ERR_INVALID;
+	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << 25 )) return RTMI_ERR_INVALID; // a batch is at least one sample of every pixel, at most 2^25 paths (META_SLOT_MASK)
 	*out = 0;
 	rtmi_ctx* c = new rtmi_ctx;
 	c->device = device_id, c->W = width, c->H = height;
@@ -1222,8 +1381,13 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		if (e && atoll( e ) >= 0) c->tail_mid = (uint32_t)atoll( e );
 		e = getenv( "RTMI_SLOTS" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= MAX_SLOTS) c->n_slots = atoi( e );
+		e = getenv( "RTMI_CARRY" );
+		if (e) c->carry_on = atoi( e ) != 0;
+		c->tail_paths = c->carry_on ? 1u << 21 : c->small_paths;
 		e = getenv( "RTMI_TAIL_PATHS" );
 		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );
+		e = getenv( "RTMI_CARRY_BOUNCE" );
+		if (e && atoi( e ) >= 0) c->carry_bounce = atoi( e );
 		e = getenv( "RTMI_STEP_BUDGET" );
 		if (e && atoi( e ) >= 0) c->budget = atoi( e );
 		e = getenv( "RTMI_REFILL" );
@@ -1235,6 +1399,14 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	c->accum = c->accum_own;
 	if (hipHostMalloc( (void**)&c->draining, 64, hipHostMallocMapped ) != hipSuccess || hipHostGetDevicePointer( (void**)&c->draining_dev, c->draining, 0 ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
 	*c->draining = 0;
+	{
+		int r = dev_alloc( c, &c->late, 4 * n ) || dev_alloc( c, &c->carry_ctr, 1 );
+		for (int k = 0; k < 2 && !r; k++)
+			r = dev_alloc( c, &c->carry[k].o_t, c->carry_cap ) || dev_alloc( c, &c->carry[k].d_h, c->carry_cap ) || dev_alloc( c, &c->carry[k].T_s, c->carry_cap ) || dev_alloc( c, &c->carry[k].meta, c->carry_cap );
+		if (r) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+		(void)hipMemset( c->late, 0, 4 * n * sizeof( long long ) );
+		(void)hipMemset( c->carry_ctr, 0, sizeof( DevCounters ) );
+	}
 	for (int k = 0; k < c->n_slots; k++)
 	{
 		BatchSlot& b = c->slots[k];
@@ -1246,6 +1418,9 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		ok = ok && hipEventCreateWithFlags( &b.bulk_done, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.acc_done, hipEventDisableTiming ) == hipSuccess;
 		if (!ok) { rtmi_destroy( c ); return RTMI_ERR_HIP; }
 		(void)hipMemset( b.ctr, 0, sizeof( DevCounters ) );
+		if (dev_alloc( c, &b.left.o_t, c->left_cap ) || dev_alloc( c, &b.left.d_h, c->left_cap ) || dev_alloc( c, &b.left.T_s, c->left_cap ) || dev_alloc( c, &b.left.meta, c->left_cap ) ||
+			dev_alloc( c, &b.n_left, 1 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
+		(void)hipMemset( b.n_left, 0, 4 );
 	}
 	(void)hipMemset( c->accum_own, 0, n * sizeof( float4 ) );
 	(void)hipMemset( c->seeds, 0, n * sizeof( uint32_t ) );
@@ -1263,11 +1438,14 @@ int rtmi_destroy( rtmi_ctx* c )
 	(void)hipDeviceSynchronize();
 	resolve_timers( c );
 	free_scene( c ), free_batches( c );
-	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->frames };
+	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->frames, c->late, c->carry_ctr,
+		c->carry[0].o_t, c->carry[0].d_h, c->carry[0].T_s, c->carry[0].meta, c->carry[1].o_t, c->carry[1].d_h, c->carry[1].T_s, c->carry[1].meta };
 	for (void* p : ps) if (p) (void)hipFree( p );
 	for (auto& b : c->slots)
 	{
 		if (b.ctr) (void)hipFree( b.ctr );
+		void* lp[] = { b.left.o_t, b.left.d_h, b.left.T_s, b.left.meta, b.n_left };
+		for (void* q : lp) if (q) (void)hipFree( q );
 		if (b.host_counts) (void)hipHostFree( b.host_counts );
 		for (int i = 0; i < 4; i++) if (b.count_ev[i]) (void)hipEventDestroy( b.count_ev[i] );
 		if (b.bulk_done) (void)hipEventDestroy( b.bulk_done );
@@ -1313,6 +1491,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 {
 	if (!c || !d) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; } // paths in flight finish in the scene they were started in
 	{ int r = sync_all( c ); if (r) return r; }
 	if (d->n_quads < 0 || d->n_spheres < 0 || d->n_cubes < 0 || d->n_planes < 0 || d->n_triangles < 0) return fail( c, RTMI_ERR_INVALID, "negative primitive count" );
 	const int nbvh = d->n_spheres + d->n_triangles;
@@ -1508,6 +1687,8 @@ int rtmi_reset_accumulator( rtmi_ctx* c )
 int rtmi_set_accumulator( rtmi_ctx* c, void* p )
 {
 	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; } // what is in flight belongs to the current accumulator
 	{ int r = sync_all( c ); if (r) return r; }
 	c->accum = p ? (float4*)p : c->accum_own;
 	return RTMI_OK;
@@ -1525,7 +1706,7 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	hipStream_t s = c->stream;
 	DevCounters* ctr = b.ctr;
 	TraceArgs a = {};
-	a.st = b.st[set], a.sq = b.sq[set], a.sq_out = b.sq[set ^ 1], a.E = b.E, a.Es = b.Es, a.wq = b.wq[set];
+	a.st = b.st[set], a.sq = b.sq[set], a.sq_out = b.sq[set ^ 1], a.sinks = make_sinks( c, b ), a.wq = b.wq[set];
 	a.count_ptr = any ? &ctr->n_shadow[set] : &ctr->n_walk[set], a.rays_ptr = &ctr->n_state[set];
 	a.pool = any ? &ctr->pool_connect : &ctr->pool_extend;
 	a.rec_in = any ? b.srec[set ^ 1] : b.rec[set ^ 1], a.rec_out = any ? b.srec[set] : b.rec[set];
@@ -1562,24 +1743,45 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	DevCounters* ctr = b.ctr;
 	if (b.busy) { HIPCHK( hipStreamWaitEvent( s, b.acc_done, 0 ) ); b.busy = false; } // the slot's previous batch is done with these buffers
 	HIPCHK( hipMemsetAsync( ctr, 0, 64, s ) ); // queue lengths and pools
-	launch_primary( c, b, N, sample_begin, stride );
+	const bool last = S == 0; // the batch of the carried paths alone (join_batches): nothing is handed on
+	if (!last) launch_primary( c, b, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
+	if (c->carry_on)
+	{
+		// the late paths that earlier batches handed on bounce along with this batch's (entries N, N+1, ...): the carry buffer
+		// (the previous batch's), and what outlived the first tail round of the batch that used this slot before -- of all
+		// slots when this is the last batch
+		auto take = [&]( PathState src, uint32_t* n_src, uint32_t cap ) {
+			hipLaunchKernelGGL( k_carry_in, dim3( ( cap + 511 ) / 512 ), dim3( 512 ), 0, s, c->ds, src, n_src, cap, b.st[0], &ctr->n_state[0], b.wq[0], ctr );
+			hipLaunchKernelGGL( k_carry_commit, dim3( 1 ), dim3( 1 ), 0, s, &ctr->n_state[0], n_src, cap );
+			upper += cap; };
+		take( c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap );
+		for (int k = 0; k < c->n_slots; k++)
+		{
+			BatchSlot& o = c->slots[k];
+			if (&o != &b && !last) continue;
+			if (&o != &b && o.busy) { HIPCHK( hipStreamWaitEvent( s, o.acc_done, 0 ) ); o.busy = false; } // its tail stream has written its list
+			take( o.left, o.n_left, c->left_cap );
+		}
+	}
 	int cur = 0;        // state / shadow queue set of this bounce
-	int clean = 0;      // bounces launched without parking since the path count fell under 4 * tail_paths
+	int clean = 0;      // consecutive bounces launched without parking
 	bool tail = false;
+	const int min_bounce = c->carry_on && !last ? c->carry_bounce : 0; // with carry, a batch that is still large stays in the loop until its paths are late
+	const uint32_t tail_paths = last ? c->small_paths : c->tail_paths;
 	for (int bounce = 0;; bounce++)
 	{
 		// Near the end of the bulk: stop parking rays (so that no suspended state is left), one bounce later hand the
-		// remaining paths to k_tail.
-		const bool prep = c->tail_paths && upper <= 4ull * c->tail_paths;
-		if (c->tail_paths && upper <= c->tail_paths && clean >= 1) { tail = true; break; }
+		// remaining paths on: the late ones to the next batch (k_carry_out), the others to this batch's k_tail.
+		const bool prep = tail_paths && ( ( upper <= 2ull * tail_paths && bounce + 2 >= min_bounce ) || upper <= 4ull * c->small_paths );
+		if (tail_paths && clean >= 1 && ( ( upper <= tail_paths && bounce >= min_bounce ) || upper <= c->small_paths )) { tail = true; break; }
 		const int budget = prep ? 0 : c->budget;
 		clean = prep ? clean + 1 : 0;
 		launch_trace( c, b, false, cur, upper, budget );
 		{
 			ScopedTimer t( c, 1 );
-			hipLaunchKernelGGL( k_shade, dim3( nsblocks( c, upper ) ), dim3( c->sblock ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], b.E, &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
+			hipLaunchKernelGGL( k_shade, dim3( nsblocks( c, upper ) ), dim3( c->sblock ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], make_sinks( c, b ), &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
 				b.wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
 		launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
@@ -1599,31 +1801,45 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		}
 		if (upper == 0) break;
 	}
+	if (tail && c->carry_on && !last)
+	{
+		// late paths -> carry buffer (they join the next batch, or join_batches finishes them); the others -> the other state set
+		hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, s, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1],
+			c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap );
+		if (c->log_bounces)
+		{
+			uint32_t rest = 0, carried = 0;
+			(void)hipStreamSynchronize( s );
+			(void)hipMemcpy( &rest, &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost ), (void)hipMemcpy( &carried, &c->carry_ctr->n_state[0], 4, hipMemcpyDeviceToHost );
+			fprintf( stderr, "rtmi: hand-over after %d bounces: %u paths carried on (buffer %u), %u stay for this batch's tail\n", (int)c->stats.bounce_launches, carried, c->carry_cap, rest );
+		}
+		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, (uint32_t*)0 );
+		cur ^= 1;
+	}
+	c->carry_pending = true; // also without carry: late sums wait to be folded
 	// the rest of the batch runs beside the next batches' bulk
 	hipStream_t ts = b.tail_stream;
 	HIPCHK( hipEventRecord( b.bulk_done, s ) );
 	HIPCHK( hipStreamWaitEvent( ts, b.bulk_done, 0 ) );
 	if (tail)
 	{
-		// rounds of 32, 64, 128, ... bounces, enqueued blind (a round over an empty queue returns at once); survivors are
-		// compacted between rounds; the last round has no limit
 		ScopedTimer t( c, 3, ts );
-		const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves );
-		for (int round = 0, len = 32; round <= 11; round++, len *= 2)
+		if (c->carry_on && !last)
 		{
-			const int limit = round == 11 ? 0x7FFFFFFF : len;
-			// waves: enough for the round's upper bound at the density the kernel will choose at most (it reads the live count)
-			const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
-			const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->stack_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
-			const uint32_t lds_words = (uint32_t)c->stack_depth * 64u * wpb;
-			hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, b.st[cur], b.st[cur ^ 1], b.E, b.Es, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, ctr );
+			// what stays with the batch are the paths that were not late yet (parked walks make a path lag): after the 32 bounces
+			// of the first round the survivors are, and wait in the slot's list for the next batch that uses the slot; only
+			// what does not fit goes through the remaining rounds
+			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 0 );
+			hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, ts, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1], b.left, b.n_left, c->left_cap );
 			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 			cur ^= 1;
+			launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), c->left_cap, 1, 11 );
 		}
+		else launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper );
 		c->stats.bounce_launches++;
 	}
 	if (c->last_acc) HIPCHK( hipStreamWaitEvent( ts, c->last_acc, 0 ) ); // accumulate in batch order
+	if (!last)
 	{
 		ScopedTimer t( c, 3, ts );
 		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, ts, c->accum, b.E, b.Es, WH, S );
@@ -1638,16 +1854,18 @@ static int fetch_counters( rtmi_ctx* c )
 {
 	int r = sync_all( c );
 	if (r) return r;
-	for (int k = 0; k < c->n_slots; k++)
+	for (int k = 0; k <= c->n_slots; k++)
 	{
 		DevCounters h;
-		HIPCHK( hipMemcpy( &h, c->slots[k].ctr, sizeof( h ), hipMemcpyDeviceToHost ) );
+		DevCounters* src = k < c->n_slots ? c->slots[k].ctr : c->carry_ctr;
+		HIPCHK( hipMemcpy( &h, src, sizeof( h ), hipMemcpyDeviceToHost ) );
 		c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
 		c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
 		c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
 		c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
 		c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
-		HIPCHK( hipMemset( c->slots[k].ctr, 0, sizeof( DevCounters ) ) );
+		// the ray counters only: the queue lengths of the carry buffer stay
+		HIPCHK( hipMemset( (char*)src + offsetof( DevCounters, extend_rays ), 0, sizeof( DevCounters ) - offsetof( DevCounters, extend_rays ) ) );
 	}
 	return RTMI_OK;
 }
@@ -1665,7 +1883,7 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
 		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
 		const char* env = getenv( "RTMI_BATCH" );
-		if (env && atoi( env ) > 0) S = std::min( sample_count, atoi( env ) );
+		if (env && atoi( env ) > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, atoi( env ) ), ( 1ll << 25 ) / WH ) );
 		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
 		for (int k = 0; k < c->n_slots; k++) { int r = ensure_batch( c, c->slots[k], S ); if (r) return r; }
 		for (int done = 0; done < sample_count; done += S)
