@@ -32,23 +32,9 @@ import os
 import sys
 import time
 
-# librtmi keeps several render batches in flight, one stream each (the long tails of a batch overlap the bulk of the next
-# ones); HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 on the GPU box) and reads that variable when the
-# runtime is loaded.  With fewer than 24 (12 batch slots + the handle's stream + torch's and RCCL's own streams: with 16 the
-# run launched by torch.distributed.run was 1.6x slower than the plain one), run the benchmark in a child process that
-# starts with 24 (nothing has touched the GPU at this point) and leave with the child's exit code.  (Under rocprofv3
-# export GPU_MAX_HW_QUEUES=24 beforehand, as
-# tools/profile_gpu.sh does, so that the profiled program is this one.)
-def _hw_queues():
-    try:
-        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-    except ValueError:
-        return 4
-
-
-if __name__ == "__main__" and _hw_queues() < 24:
-    import subprocess
-    sys.exit(subprocess.call([sys.executable] + sys.argv, env=dict(os.environ, GPU_MAX_HW_QUEUES="24")))
+# (librtmi keeps a few render batches in flight, one HIP stream each; since the late paths of a batch ride with the next
+# batches those streams carry milliseconds of work and HIP's default of 4 hardware queues is enough:
+# no GPU_MAX_HW_QUEUES setting is needed, here or under torch.distributed.run.)
 
 import numpy as np
 

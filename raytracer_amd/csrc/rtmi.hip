@@ -1366,7 +1366,8 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		// batches in flight: each uses its own stream, and streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES,
 		// 4 unless the process raises it before HIP starts) serialise behind each other
 		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
-		c->n_slots = ( q && atoi( q ) >= 13 ) ? 12 : ( q && atoi( q ) >= 7 ) ? 6 : 4;
+		if (getenv( "RTMI_CARRY" )) c->carry_on = atoi( getenv( "RTMI_CARRY" ) ) != 0;
+		c->n_slots = c->carry_on || !q || atoi( q ) < 7 ? 4 : atoi( q ) >= 13 ? 12 : 6; // whole tails (RTMI_CARRY=0) last 0.5 s: more batches in flight
 		const char* e = getenv( "RTMI_TAIL_LANES" );
 		if (e) { const int v = atoi( e ); if (v >= 1 && v <= 64 && ( v & ( v - 1 ) ) == 0) c->tail_lanes = v; }
 		e = getenv( "RTMI_TAIL_WAVES" );
@@ -1381,8 +1382,6 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		if (e && atoll( e ) >= 0) c->tail_mid = (uint32_t)atoll( e );
 		e = getenv( "RTMI_SLOTS" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= MAX_SLOTS) c->n_slots = atoi( e );
-		e = getenv( "RTMI_CARRY" );
-		if (e) c->carry_on = atoi( e ) != 0;
 		c->tail_paths = c->carry_on ? 1u << 21 : c->small_paths;
 		e = getenv( "RTMI_TAIL_PATHS" );
 		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
-export GPU_MAX_HW_QUEUES=24 # bench.py would otherwise start a child process with it: under rocprofv3 the program must be the one after --
+
 BENCH="python3 bench.py --steps 4 --warmup 1 --spp-per-step 16 --no-cpu-baseline"
 timeout -s KILL 60 rocprofv3 -L > $OUT/counters_available.txt 2>&1 || true
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
