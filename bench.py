@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=64, help="samples per pixel per step per GPU (configs[2]: 64 spp progressive)")
     ap.add_argument("--tris", type=int, default=1000000)
@@ -131,6 +131,7 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    dev.flush()  # the late paths of the warm-up batches finish (and are folded into the accumulator) before it is cleared
     barrier()
     acc.zero_()
     dev.set_profiling(True, False)
