@@ -135,6 +135,26 @@ def test_full_size_image_and_properties(full):
     finally:
         del os.environ["RTMI_BATCH"]
     assert np.array_equal(bits(d.accumulator()), bits(four))
+    # late paths (from their 15th vertex on) ride the following batches and add to an exact per-pixel sum;
+    # with RTMI_CARRY=0 every batch finishes all of its paths in a tail of its own.  Same paths, same arithmetic: the images
+    # differ by float summation order only
+    os.environ["RTMI_CARRY"] = "0"
+    try:
+        d0 = api.Device(W, H)
+    finally:
+        del os.environ["RTMI_CARRY"]
+    d0.upload(scene.desc)
+    d0.set_seeds(seeds)
+    d0.set_camera(api.default_camera(W, H, scene.scale))
+    d0.render(api.PATHTRACING, 0, 4, 1)
+    assert np.allclose(d0.accumulator(), four, rtol=2e-6, atol=1e-6)
+    d0.close()
+    # progressive reads: reading the image between renders (late sums are folded at every read) changes rounding only
+    d.reset()
+    d.render(api.PATHTRACING, 0, 2, 1)
+    d.accumulator()
+    d.render(api.PATHTRACING, 2, 2, 1)
+    assert np.allclose(d.accumulator(), four, rtol=2e-6, atol=1e-6)
     # sample split: even + odd samples on "two ranks" sum to the same image up to float summation order
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 2)

@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 
-BENCH="python3 bench.py --steps 2 --warmup 1 --spp-per-step 16 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 timeout -s KILL 300 rocprofv3 --pmc TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_ta -o pmc -- $BENCH > $OUT/pmc_ta.log 2>&1 || { echo "pmc ta failed"; tail -5 $OUT/pmc_ta.log; exit 1; }
 python3 - $OUT <<'PY'
 import csv, glob, sys, os, collections

@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 
-BENCH="python3 bench.py --steps 4 --warmup 1 --spp-per-step 16 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 timeout -s KILL 60 rocprofv3 -L > $OUT/counters_available.txt 2>&1 || true
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; exit 1; }

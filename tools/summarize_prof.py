@@ -35,7 +35,7 @@ def main(out):
             a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
             per[k].append((d, r.get("Grid_Size", "?"), r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?")))
     total = sum(a[1] for a in agg.values()) or 1
-    print("== kernel trace (rocprofv3 --kernel-trace --stats), bench.py --steps 4 --warmup 1 --spp-per-step 16 (incl. counting pass + warmup) ==")
+    print("== kernel trace (rocprofv3 --kernel-trace --stats), bench.py --steps 3 --warmup 1 (incl. counting pass + warmup) ==")
     print("%-28s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-28s %8d %12.1f %10.2f %10.2f %10.1f %6.1f" % (k, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / total))

@@ -24,7 +24,7 @@ def sums(d, sub, counter):
 
 d, out = sys.argv[1], sys.argv[2]
 fetch, write = sums(d, "pmc_fetch", "FETCH_SIZE"), sums(d, "pmc_write", "WRITE_SIZE")
-res = {"source": os.path.basename(d.rstrip("/")), "command": "bench.py --steps 4 --warmup 1 --spp-per-step 16 --no-cpu-baseline (tools/profile_gpu.sh)", "unit": "bytes per launch",
+res = {"source": os.path.basename(d.rstrip("/")), "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline (tools/profile_gpu.sh)", "unit": "bytes per launch",
        "correction": "2 x FETCH_SIZE (gfx950, 16-B/lane loads) + WRITE_SIZE, KiB -> bytes", "kernels": {}}
 for k in fetch:
     f, nf = fetch[k]; w, nw = write.get(k, (0.0, nf))
