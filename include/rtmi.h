@@ -149,10 +149,13 @@ int rtmi_postprocess( rtmi_ctx*, uint32_t* rgb8_inout, int width, int height, co
 int rtmi_read_accumulator( rtmi_ctx*, float* rgba_out );
 int rtmi_synchronize( rtmi_ctx* );
 /* No reference counterpart (its queues are in-order and Tick blocks on every read-back, renderer.cpp:538-556).
- * rtmi_render returns with work still enqueued on the handle's stream AND on internal streams (the tails of render
- * batches overlap the next batches).  Every rtmi_* call that reads or resets the accumulator orders itself after that
- * work; a caller that consumes a caller-owned accumulator (rtmi_set_accumulator) on its own stream calls rtmi_flush
- * first: non-blocking, it makes the handle's stream wait for everything rendered so far. */
+ * rtmi_render returns with work still enqueued on the handle's stream AND on internal streams, and with paths still
+ * in flight: paths that are alive after many bounces travel on with the next render batches, and what they contribute
+ * is kept in exact per-pixel sums beside the accumulator.  Every rtmi_* call that reads or resets the accumulator first
+ * finishes those paths, adds the sums to the accumulator and orders itself after all of it; a caller that consumes a
+ * caller-owned accumulator (rtmi_set_accumulator) on its own stream calls rtmi_flush first: non-blocking for the host,
+ * it enqueues that completion and makes the handle's stream wait for everything rendered so far.  The accumulator is
+ * the sum of whole samples only after one of these calls. */
 int rtmi_flush( rtmi_ctx* );
 
 /* Counters and timing (the reference only prints a frame time, renderer.cpp:635-641). */
