@@ -1776,7 +1776,10 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	{
 		// Near the end of the bulk: stop parking rays (so that no suspended state is left), one bounce later hand the
 		// remaining paths on: the late ones to the next batch (k_carry_out), the others to this batch's k_tail.
-		const bool prep = tail_paths && ( ( upper <= 2ull * tail_paths && bounce + 2 >= min_bounce ) || upper <= 4ull * c->small_paths );
+		// (a launch without parking lasts as long as its longest ray, 3x the parked one at this size: only the bounce before
+		// the hand-over runs that way; `upper` is two bounces old and the path count falls by about 0.83 per bounce)
+		const unsigned long long soon = (unsigned long long)( upper * 0.85 );
+		const bool prep = tail_paths && ( ( soon <= tail_paths && bounce + 1 >= min_bounce ) || soon <= c->small_paths );
 		if (tail_paths && clean >= 1 && ( ( upper <= tail_paths && bounce >= min_bounce ) || upper <= c->small_paths )) { tail = true; break; }
 		const int budget = prep ? 0 : c->budget;
 		clean = prep ? clean + 1 : 0;
