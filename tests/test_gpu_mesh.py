@@ -155,6 +155,23 @@ def test_full_size_image_and_properties(full):
     d.accumulator()
     d.render(api.PATHTRACING, 2, 2, 1)
     assert np.allclose(d.accumulator(), four, rtol=2e-6, atol=1e-6)
+    # paths in flight across calls: two renders without a read in between, a parity hook in between, == one render
+    d.reset()
+    d.render(api.PATHTRACING, 0, 2, 1)
+    d.trace_primary()
+    d.render(api.PATHTRACING, 2, 2, 1)
+    assert np.array_equal(bits(d.accumulator()), bits(four))
+    # a reset with paths in flight discards nothing it should keep and keeps nothing it should discard
+    d.reset()
+    d.render(api.PATHTRACING, 7, 3, 1)
+    d.reset()
+    d.render(api.PATHTRACING, 0, 4, 1)
+    assert np.array_equal(bits(d.accumulator()), bits(four))
+    # a scene upload with paths in flight: they finish in the scene they were started in
+    d.reset()
+    d.render(api.PATHTRACING, 0, 4, 1)
+    d.upload(scene.desc)
+    assert np.array_equal(bits(d.accumulator()), bits(four))
     # sample split: even + odd samples on "two ranks" sum to the same image up to float summation order
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 2)
