@@ -1173,7 +1173,7 @@ struct rtmi_ctx
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
 	int sblock = 512;            // threads per block of k_primary / k_shade (RTMI_SBLOCK): blocks of 16 waves wait for a CU with 4 free
 	                             // slots on every SIMD, which the long-lived tail waves of earlier batches rarely leave
-	int tail_waves = 8;          // resident k_tail waves per CU
+	int tail_waves = 16;         // resident k_tail waves per CU
 	int tail_block = 4;          // waves per k_tail workgroup (RTMI_TAIL_BLOCK)
 	uint32_t tail_dense = 4096, tail_mid = 0; // k_tail: 64 paths per wave above tail_dense live paths, 16 above tail_mid, else tail_lanes
 	bool log_bounces = false;   // RTMI_LOG_BOUNCES: print the path count per bounce (diagnostics)
