@@ -10,6 +10,9 @@
 //                       queue order to the other state set, BVH walkers are appended to the walk / shadow queues with
 //                       one atomic per 1024-thread block (ballot + mbcnt prefix per wave, LDS scan across waves)
 //   k_trace<any>        any-hit walk of the shadow queue, E[slot] += contribution          (scene.h:369-379, renderer.cpp:339-344)
+//   k_carry_out / _in   the paths still alive when a batch leaves the bounce loop are late (>= 15 vertices: they add to an
+//                       exact per-pixel sum, see Sinks) and join the next batch's queue; k_tail runs what is left of a
+//                       render's paths to their ends when the caller reads the image
 //   k_accumulate        accumulator[p] += E[sample][p] in sample order                    (renderer.cpp:566-567)
 //   k_finalize, k_gamma, k_chroma, k_vignette                                             (precomp.h:431-465, postprocessing.h)
 //   k_whitted           Renderer::Trace for the non-path-tracing modes, one thread per pixel with an explicit
@@ -1110,10 +1113,10 @@ __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int
 // =================================================================================================================
 // host side
 // =================================================================================================================
-// One render batch in flight.  The bulk bounces of a batch run on the handle's stream; its tail (k_tail: the last paths,
-// some of which live for thousands of bounces) and its k_accumulate run on the slot's own stream, so that they overlap
-// the bulk bounces of the following batches.  k_accumulate launches are chained by events in batch order (the
-// accumulator sums samples in sample order, renderer.cpp:566-567).
+// One render batch in flight.  The bulk bounces of a batch run on the handle's stream; one k_tail round for the few paths
+// that are not late at the hand-over (with RTMI_CARRY=0: the whole tail) and its k_accumulate run on the slot's own stream,
+// so that they overlap the bulk bounces of the following batches.  k_accumulate launches are chained by events in batch
+// order (the accumulator sums samples in sample order, renderer.cpp:566-567).
 #define MAX_SLOTS 16
 struct BatchSlot
 {
