@@ -255,7 +255,9 @@ class HostScene:
 
     @property
     def desc(self):
-        return self.L.rth_scene_desc(self.h).contents
+        d = self.L.rth_scene_desc(self.h).contents
+        d._owner = self  # the descriptor points into this scene: keep it alive as long as the descriptor is
+        return d
 
     def info(self):
         out = np.zeros(7, np.int32)
