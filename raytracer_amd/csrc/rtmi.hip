@@ -659,7 +659,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
 __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t hurry_single, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
@@ -671,9 +671,18 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	// The grid is a bounded number of resident waves that pull per_wave paths at a time.
 	const uint32_t n = *n_in;
 	// `draining` (pinned host memory): the host has nothing more to enqueue and waits for the tails (rtmi_flush, read-backs):
-	// from then on a round with no more than 4 * dense_above paths runs for latency, 4 paths to a wave (round 0 excepted)
-	const bool hurry = dense_above != 0 && n <= 4 * dense_above && *(const volatile uint32_t*)draining != 0;
-	const int per_wave = hurry ? ( n <= hurry_single ? 1 : 4 ) : n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
+	// the chip is this kernel's, so a round (round 0 excepted) spreads its paths over all the waves of the grid, as few to a
+	// wave as that allows: a path's bounce waits for the walks of the others in its wave
+	const bool hurry = dense_above != 0 && *(const volatile uint32_t*)draining != 0;
+	int per_wave;
+	if (hurry)
+	{
+		const uint32_t waves = gridDim.x * ( blockDim.x >> 6 );
+		const uint32_t need = ( n + waves - 1 ) / waves;
+		per_wave = 1;
+		while ((uint32_t)per_wave < need && per_wave < 64) per_wave *= 2;
+	}
+	else per_wave = n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
 	const uint32_t stride = 64u / (uint32_t)per_wave;
 	// Workgroups of several waves: the waves of this kernel live for milliseconds, and a CU that hosts one serves the
 	// blocks of the next batches' k_shade at about half speed (the old wave wins the issue arbitration; the block's barriers
@@ -1169,7 +1178,6 @@ struct rtmi_ctx
 	bool carry_on = true;        // RTMI_CARRY=0: every batch finishes all of its paths in its own tail
 	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
 	uint32_t small_paths = 1u << 18; // a batch with no more paths than this leaves the wavefront loop at once
-	uint32_t hurry_single = 16384; // a draining round with no more paths than this runs one path per wave (RTMI_HURRY_SINGLE)
 	int carry_bounce = 17;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
 	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
@@ -1301,7 +1309,7 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->stack_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
 		const uint32_t lds_words = (uint32_t)c->stack_depth * 64u * wpb;
 		hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-			round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, c->hurry_single, ctr );
+			round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, ctr );
 		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 		cur ^= 1;
 	}
@@ -1389,8 +1397,6 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		c->tail_paths = c->carry_on ? 1u << 21 : c->small_paths;
 		e = getenv( "RTMI_TAIL_PATHS" );
 		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );
-		e = getenv( "RTMI_HURRY_SINGLE" );
-		if (e && atoll( e ) >= 0) c->hurry_single = (uint32_t)atoll( e );
 		e = getenv( "RTMI_CARRY_BOUNCE" );
 		if (e && atoi( e ) >= 0) c->carry_bounce = atoi( e );
 		e = getenv( "RTMI_STEP_BUDGET" );
