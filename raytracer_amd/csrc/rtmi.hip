@@ -1397,6 +1397,10 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		c->tail_paths = c->carry_on ? 1u << 21 : c->small_paths;
 		e = getenv( "RTMI_TAIL_PATHS" );
 		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );
+		e = getenv( "RTMI_CARRY_CAP" ); // (tests: small buffers exercise the paths taken when they are full)
+		if (e && atoll( e ) >= 1 && atoll( e ) <= ( 1ll << 24 )) c->carry_cap = (uint32_t)atoll( e );
+		e = getenv( "RTMI_LEFT_CAP" );
+		if (e && atoll( e ) >= 1 && atoll( e ) <= ( 1ll << 20 )) c->left_cap = (uint32_t)atoll( e );
 		e = getenv( "RTMI_CARRY_BOUNCE" );
 		if (e && atoi( e ) >= 0) c->carry_bounce = atoi( e );
 		e = getenv( "RTMI_STEP_BUDGET" );

@@ -149,6 +149,19 @@ def test_full_size_image_and_properties(full):
     d0.render(api.PATHTRACING, 0, 4, 1)
     assert np.allclose(d0.accumulator(), four, rtol=2e-6, atol=1e-6)
     d0.close()
+    # full buffers: with a carry buffer of 1000 paths and slot lists of 100 nearly every survivor takes the fall-back route
+    # (the batch's own k_tail rounds); the image must not change by a bit
+    os.environ["RTMI_CARRY_CAP"], os.environ["RTMI_LEFT_CAP"] = "1000", "100"
+    try:
+        d1 = api.Device(W, H)
+    finally:
+        del os.environ["RTMI_CARRY_CAP"], os.environ["RTMI_LEFT_CAP"]
+    d1.upload(scene.desc)
+    d1.set_seeds(seeds)
+    d1.set_camera(api.default_camera(W, H, scene.scale))
+    d1.render(api.PATHTRACING, 0, 4, 1)
+    assert np.array_equal(bits(d1.accumulator()), bits(four))
+    d1.close()
     # progressive reads: reading the image between renders (late sums are folded at every read) changes rounding only
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 1)
