@@ -77,8 +77,12 @@ struct DScene
 	// leaf-ordered primitive records (position k == primitiveIdx[k]), 48 B: triangle {p1, tag 0} {e1, objIdx} {e2, -}
 	// sphere {pos, tag 1} {r2,0,0, objIdx} {-}
 	const float4* __restrict__ prims;
+	// 4-wide interior nodes with quantised boxes over the same leaves (wide_step below; null: not built), the exact box of
+	// every leaf at [2 * first primitive position], and the wide root
+	const float4* __restrict__ wide;
+	const float4* __restrict__ leafbox;
 	float root_min[3], root_max[3];
-	uint32_t root_ref;
+	uint32_t root_ref, wide_root;
 	int n_quads, n_spheres, n_cubes, n_planes, n_tris, n_bvh_prims;
 	const float4* __restrict__ quads;   // per quad 4 x float4: invT rows 0..2, {size,0,0,0}
 	const float4* __restrict__ cubes;   // per cube 8 x float4: invM rows 0..2, b0, b1, M rows 0..2
@@ -300,6 +304,65 @@ __device__ __forceinline__ uint32_t interior_step( const DScene& s, uint32_t cur
 	if (hitR) return refR;
 	if (sp > 0) return stack[--sp * stride];
 	return RT_DONE;
+}
+
+// ---- 4-wide nodes with quantised child boxes (the walk kernels' interior nodes; built on upload from the pair array) ----
+// One 64-byte record holds up to four children: {origin.xyz, scale exponents} {4 refs} {lo.x[4] lo.y[4] lo.z[4] hi.x[4]}
+// {hi.y[4] hi.z[4] - -}, one byte per child and plane.  A plane is origin + byte * 2^e (one fma, checked on the host
+// with the same fma to lie on or outside the child's exact box), and the slab test on it is the reference's formula
+// (b - O) * rD, which is monotone in b: whenever the exact box of a node passes the test, so do these boxes of all its
+// ancestors.  Passing the exact test of a LEAF's box therefore implies passing the exact tests of the whole chain the
+// reference walks to reach it (bvh.h:507-530), and the set of primitives that may be accepted is unchanged as long as
+// every accepted hit is confirmed against the exact box of its leaf (s.leafbox, in k_trace).  Halves the number of
+// dependent fetches per ray.  Needs finite reciprocal directions (no NaN in the slab test): other rays walk the pairs.
+__device__ __forceinline__ float wide_byte( uint32_t w, int c ) { return (float)( ( w >> ( 8 * c ) ) & 255u ); } // v_cvt_f32_ubyteN
+template <bool ANY>
+__device__ __forceinline__ uint32_t wide_step( const DScene& s, uint32_t cur, f3 O, f3 rD, float t, uint32_t* stack, const int stride, int& sp )
+{
+	const float4 q0 = s.wide[4 * cur], q1 = s.wide[4 * cur + 1], q2 = s.wide[4 * cur + 2], q3 = s.wide[4 * cur + 3];
+	const uint32_t ex = __float_as_uint( q0.w );
+	const float sx = __uint_as_float( ( ex & 255u ) << 23 ), sy = __uint_as_float( ( ( ex >> 8 ) & 255u ) << 23 ), sz = __uint_as_float( ( ( ex >> 16 ) & 255u ) << 23 );
+	const uint32_t lox = __float_as_uint( q2.x ), loy = __float_as_uint( q2.y ), loz = __float_as_uint( q2.z );
+	const uint32_t hix = __float_as_uint( q2.w ), hiy = __float_as_uint( q3.x ), hiz = __float_as_uint( q3.y );
+	// entry and exit plane of each axis by the sign of the direction: min(tx1, tx2) of bvh.h:445-450 without the min
+	const uint32_t nx = rD.x < 0 ? hix : lox, fx = rD.x < 0 ? lox : hix;
+	const uint32_t ny = rD.y < 0 ? hiy : loy, fy = rD.y < 0 ? loy : hiy;
+	const uint32_t nz = rD.z < 0 ? hiz : loz, fz = rD.z < 0 ? loz : hiz;
+	const uint32_t ref[4] = { __float_as_uint( q1.x ), __float_as_uint( q1.y ), __float_as_uint( q1.z ), __float_as_uint( q1.w ) };
+	uint32_t key[4];
+	// two children at a time: gfx950 has packed binary32 fma / add / mul (v_pk_*_f32), each lane of a pair rounds as the scalar form
+	typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
+	const v2f Sx = { sx, sx }, Sy = { sy, sy }, Sz = { sz, sz }, Bx = { q0.x, q0.x }, By = { q0.y, q0.y }, Bz = { q0.z, q0.z };
+	const v2f Ox = { O.x, O.x }, Oy = { O.y, O.y }, Oz = { O.z, O.z }, Rx = { rD.x, rD.x }, Ry = { rD.y, rD.y }, Rz = { rD.z, rD.z };
+#pragma unroll
+	for (int c = 0; c < 4; c += 2)
+	{
+		const v2f qnx = { wide_byte( nx, c ), wide_byte( nx, c + 1 ) }, qfx = { wide_byte( fx, c ), wide_byte( fx, c + 1 ) };
+		const v2f qny = { wide_byte( ny, c ), wide_byte( ny, c + 1 ) }, qfy = { wide_byte( fy, c ), wide_byte( fy, c + 1 ) };
+		const v2f qnz = { wide_byte( nz, c ), wide_byte( nz, c + 1 ) }, qfz = { wide_byte( fz, c ), wide_byte( fz, c + 1 ) };
+		const v2f tnx = ( __builtin_elementwise_fma( qnx, Sx, Bx ) - Ox ) * Rx, tfx = ( __builtin_elementwise_fma( qfx, Sx, Bx ) - Ox ) * Rx;
+		const v2f tny = ( __builtin_elementwise_fma( qny, Sy, By ) - Oy ) * Ry, tfy = ( __builtin_elementwise_fma( qfy, Sy, By ) - Oy ) * Ry;
+		const v2f tnz = ( __builtin_elementwise_fma( qnz, Sz, Bz ) - Oz ) * Rz, tfz = ( __builtin_elementwise_fma( qfz, Sz, Bz ) - Oz ) * Rz;
+#pragma unroll
+		for (int j = 0; j < 2; j++)
+		{
+			const float tmin = fmaxf( fmaxf( tnx[j], tny[j] ), tnz[j] ), tmax = fminf( fminf( tfx[j], tfy[j] ), tfz[j] );
+			const bool hit = tmax >= tmin && ( ANY ? tmin < t : tmin <= t ) && tmax > 0 && ref[c + j] != RT_DONE;
+			// order key: entry distance (clamped at 0) with the child number in the two lowest bits
+			key[c + j] = hit ? ( ( __float_as_uint( fmaxf( tmin, 0.0f ) ) & ~3u ) | (uint32_t)( c + j ) ) : 0xFFFFFFFFu;
+		}
+	}
+#define RT_CSWAP( a, b ) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_, key[b] = hi_; }
+	RT_CSWAP( 0, 1 ) RT_CSWAP( 2, 3 ) RT_CSWAP( 0, 2 ) RT_CSWAP( 1, 3 ) RT_CSWAP( 1, 2 )
+#undef RT_CSWAP
+#define RT_PICK( k ) ( ( ( k ) & 2u ) ? ( ( ( k ) & 1u ) ? ref[3] : ref[2] ) : ( ( ( k ) & 1u ) ? ref[1] : ref[0] ) )
+	if (key[0] == 0xFFFFFFFFu) return sp > 0 ? stack[--sp * stride] : RT_DONE;
+	// the nearest child next, the others on the stack, farthest deepest
+	if (key[3] != 0xFFFFFFFFu) { stack[sp * stride] = RT_PICK( key[3] ); sp++; }
+	if (key[2] != 0xFFFFFFFFu) { stack[sp * stride] = RT_PICK( key[2] ); sp++; }
+	if (key[1] != 0xFFFFFFFFu) { stack[sp * stride] = RT_PICK( key[1] ); sp++; }
+	return RT_PICK( key[0] );
+#undef RT_PICK
 }
 
 // Scene::FindNearest (scene.h:359-368): quads[0], cubes[0], planes, BVH.  h.t carries the ray's tmax in.

@@ -278,6 +278,9 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	const uint32_t n = *a.count_ptr;
 	const int lane = threadIdx.x & 63;
 	const int refill = a.refill;
+	// interior nodes: the 4-wide quantised records where they were built; rays with an infinite reciprocal direction
+	// component (`inexact`) and the counting pass (which counts the reference's nodes) walk the pairs
+	const bool use_wide = !COUNT && s.wide != nullptr;
 	// chunk: large enough that the pool counter is not the bottleneck, small enough that the last chunks balance
 	const uint32_t waves = gridDim.x * ( BLOCK / 64 );
 	uint32_t chunk = n / ( waves * 4u );
@@ -357,6 +360,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 						}
 						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 						inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+						if (use_wide && !inexact && !resumed) cur = s.wide_root;
 					}
 					chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
 					if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
@@ -424,7 +428,12 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 		const bool atNode = has && !( cur & RT_LEAF ), atLeaf = has && ( cur & RT_LEAF ) && cur != RT_DONE;
 		if (__popcll( __ballot( atNode ) ) >= __popcll( __ballot( atLeaf ) ))
 		{
-			if (__ballot( has && inexact ) != 0)
+			if (use_wide)
+			{
+				if (atNode && !inexact) cur = wide_step<ANY>( s, cur, O, rD, h.t, stack, BLOCK, sp );
+				if (__ballot( atNode && inexact ) != 0) { if (atNode && inexact) cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+			}
+			else if (__ballot( has && inexact ) != 0)
 			{
 				if (atNode) { if (COUNT) tc.pairs++, steps++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
 			}
@@ -434,7 +443,17 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 		{
 			const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
 			if (COUNT) tc.prims++, steps++;
-			const bool hit = isect_prim<ANY>( s, first + k, O, D, h );
+			const float t0 = h.t;
+			const int obj0 = h.obj, pos0 = h.pos;
+			bool hit = isect_prim<ANY>( s, first + k, O, D, h );
+			if (hit && use_wide && !inexact)
+			{
+				// reached through quantised boxes: the hit counts only if the leaf's exact box passes the reference's test
+				const float4 b0 = s.leafbox[2 * first], b1 = s.leafbox[2 * first + 1];
+				float tmn, tmx;
+				slab<false>( b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, O, rD, tmn, tmx );
+				if (!( tmx >= tmn && ( ANY ? tmn < t0 : tmn <= t0 ) && tmx > 0 )) hit = false, h.t = t0, h.obj = obj0, h.pos = pos0;
+			}
 			k++;
 			if (ANY && hit) occluded = true, cur = RT_DONE, k = 0;
 			else if (k == count) k = 0, cur = sp > 0 ? stack[--sp * BLOCK] : RT_DONE;
@@ -1157,7 +1176,9 @@ struct rtmi_ctx
 	bool has_scene = false;
 	DScene ds = {};
 	std::vector<void*> scene_allocs;
-	int stack_depth = 8;
+	int stack_depth = 8;         // per-lane traversal stack over the pairs (k_tail, k_whitted, k_trace_rays)
+	int walk_depth = 8;          // same for k_trace: the larger need of the pairs and of the 4-wide nodes; sizes the suspend records
+	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
 	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
 	int n_cus = 256;
@@ -1280,7 +1301,7 @@ static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 	free_batch( b );
 	const size_t n0 = (size_t)S * c->W * c->H, n = n0 + c->carry_cap + (size_t)MAX_SLOTS * c->left_cap; // the queues also hold the paths carried in from earlier batches
 	const size_t cap = n / 8 + 1024;
-	b.rec_stride = c->stack_depth + REC_HEADER;
+	b.rec_stride = c->walk_depth + REC_HEADER;
 	int r = RTMI_OK;
 	for (int k = 0; k < 2 && !r; k++)
 		( r = dev_alloc( c, &b.st[k].o_t, n ) ) || ( r = dev_alloc( c, &b.st[k].d_h, n ) ) || ( r = dev_alloc( c, &b.st[k].T_s, n ) ) || ( r = dev_alloc( c, &b.st[k].meta, n ) ) ||
@@ -1378,6 +1399,7 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		// batches in flight: each uses its own stream, and streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES,
 		// 4 unless the process raises it before HIP starts) serialise behind each other
 		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
+		if (getenv( "RTMI_WIDE" )) c->wide_on = atoi( getenv( "RTMI_WIDE" ) ) != 0;
 		if (getenv( "RTMI_CARRY" )) c->carry_on = atoi( getenv( "RTMI_CARRY" ) ) != 0;
 		c->n_slots = c->carry_on || !q || atoi( q ) < 7 ? 4 : atoi( q ) >= 13 ? 12 : 6; // whole tails (RTMI_CARRY=0) last 0.5 s: more batches in flight
 		const char* e = getenv( "RTMI_TAIL_LANES" );
@@ -1500,6 +1522,108 @@ int rtmi_flush( rtmi_ctx* c )
 	return join_batches( c );
 }
 
+// ---- 4-wide nodes with quantised boxes over the pair array (rt_device.h: wide_step) --------------------------------
+// Collapse: the node of pair p starts with p's two children; while it has room, the interior child with the largest
+// surface area is replaced by its own two children.  Each plane of a child box becomes one byte q with
+// fma(q, 2^e, origin) <= exact lower bound (>= exact upper bound), checked here with the fma the kernel executes.
+// Also writes the exact box of every leaf at leafbox[2 * first].  Returns the deepest stack a traversal can need
+// (sum over a root-to-leaf chain of children - 1), or -1.
+static int build_wide_nodes( const std::vector<float4>& pairs, uint32_t root_pair, int nbvh, std::vector<float4>& wide, std::vector<float4>& leafbox )
+{
+	struct Child { float mn[3], mx[3]; uint32_t ref; };
+	struct Work { uint32_t pair, node; int above; };
+	auto child_of = [&]( uint32_t pair, int side ) {
+		const float4 a = pairs[4 * (size_t)pair + 2 * side], b = pairs[4 * (size_t)pair + 2 * side + 1];
+		Child ch; ch.mn[0] = a.x, ch.mn[1] = a.y, ch.mn[2] = a.z, ch.mx[0] = a.w, ch.mx[1] = b.x, ch.mx[2] = b.y;
+		memcpy( &ch.ref, &b.z, 4 );
+		return ch; };
+	auto area = []( const Child& ch ) {
+		const double dx = (double)ch.mx[0] - ch.mn[0], dy = (double)ch.mx[1] - ch.mn[1], dz = (double)ch.mx[2] - ch.mn[2];
+		return dx * dy + dy * dz + dz * dx; };
+	leafbox.assign( (size_t)std::max( nbvh, 1 ) * 2, make_float4( 0, 0, 0, 0 ) );
+	wide.assign( 4, make_float4( 0, 0, 0, 0 ) );
+	std::vector<Work> work;
+	work.push_back( { root_pair, 0u, 0 } );
+	int deepest = 0;
+	while (!work.empty())
+	{
+		const Work w = work.back();
+		work.pop_back();
+		Child ch[4];
+		int n = 2;
+		ch[0] = child_of( w.pair, 0 ), ch[1] = child_of( w.pair, 1 );
+		while (n < 4)
+		{
+			int best = -1;
+			double bestArea = -1;
+			for (int i = 0; i < n; i++) if (!( ch[i].ref & RT_LEAF ) && area( ch[i] ) > bestArea) best = i, bestArea = area( ch[i] );
+			if (best < 0) break;
+			const uint32_t p = ch[best].ref;
+			ch[best] = child_of( p, 0 ), ch[n++] = child_of( p, 1 );
+		}
+		const int above = w.above + n - 1;
+		deepest = std::max( deepest, above );
+		float o[3];
+		uint32_t ebits = 0, lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+		for (int ax = 0; ax < 3; ax++)
+		{
+			float mn = ch[0].mn[ax], mx = ch[0].mx[ax];
+			for (int i = 1; i < n; i++) mn = std::min( mn, ch[i].mn[ax] ), mx = std::max( mx, ch[i].mx[ax] );
+			if (!( mn <= mx ) || !std::isfinite( mn ) || !std::isfinite( mx )) return -1;
+			o[ax] = mn;
+			int e = 1; // biased exponent of the step 2^(e-127); smallest with 255 steps >= extent
+			const double extent = (double)mx - (double)mn;
+			while (e < 254 && 255.0 * std::ldexp( 1.0, e - 127 ) < extent) e++;
+			for (;; e++)
+			{
+				if (e > 254) return -1;
+				const float step = std::ldexp( 1.0f, e - 127 );
+				bool ok = true;
+				uint32_t l = 0, h = 0;
+				for (int i = 0; i < 4 && ok; i++)
+				{
+					int ql = 255, qh = 0; // an empty slot: inverted box
+					if (i < n)
+					{
+						ql = (int)std::floor( ( (double)ch[i].mn[ax] - mn ) / step ), qh = (int)std::ceil( ( (double)ch[i].mx[ax] - mn ) / step );
+						ql = std::max( 0, std::min( 255, ql ) ), qh = std::max( 0, qh );
+						while (ql > 0 && std::fmaf( (float)ql, step, mn ) > ch[i].mn[ax]) ql--;
+						while (qh <= 255 && std::fmaf( (float)std::min( qh, 255 ), step, mn ) < ch[i].mx[ax]) qh++;
+						if (qh > 255 || std::fmaf( (float)ql, step, mn ) > ch[i].mn[ax]) ok = false;
+					}
+					l |= (uint32_t)ql << ( 8 * i ), h |= (uint32_t)( qh & 255 ) << ( 8 * i );
+				}
+				if (ok) { lo[ax] = l, hi[ax] = h; break; }
+			}
+			ebits |= (uint32_t)e << ( 8 * ax );
+		}
+		uint32_t ref[4] = { RT_DONE, RT_DONE, RT_DONE, RT_DONE };
+		for (int i = 0; i < n; i++)
+		{
+			if (ch[i].ref & RT_LEAF)
+			{
+				ref[i] = ch[i].ref;
+				const size_t first = ch[i].ref & RT_LEAF_FIRST_MASK;
+				leafbox[2 * first] = make_float4( ch[i].mn[0], ch[i].mn[1], ch[i].mn[2], ch[i].mx[0] );
+				leafbox[2 * first + 1] = make_float4( ch[i].mx[1], ch[i].mx[2], 0, 0 );
+			}
+			else
+			{
+				ref[i] = (uint32_t)( wide.size() / 4 );
+				wide.resize( wide.size() + 4, make_float4( 0, 0, 0, 0 ) );
+				work.push_back( { ch[i].ref, ref[i], above } );
+			}
+		}
+		auto f = []( uint32_t u ) { float v; memcpy( &v, &u, 4 ); return v; };
+		float4* q = &wide[4 * (size_t)w.node];
+		q[0] = make_float4( o[0], o[1], o[2], f( ebits ) );
+		q[1] = make_float4( f( ref[0] ), f( ref[1] ), f( ref[2] ), f( ref[3] ) );
+		q[2] = make_float4( f( lo[0] ), f( lo[1] ), f( lo[2] ), f( hi[0] ) );
+		q[3] = make_float4( f( hi[1] ), f( hi[2] ), 0, 0 );
+	}
+	return deepest;
+}
+
 // Validates the reference-layout node array and repacks it: pair k = nodes[3+2k], nodes[4+2k] (the reference
 // allocates children in adjacent pairs starting at node 3), interior leftFirst -> pair index, leaf -> encoded range.
 int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
@@ -1523,7 +1647,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	std::vector<void*> allocs;
 	auto bail = [&]( int code ) { for (void* p : allocs) (void)hipFree( p ); return code; };
 	int r;
-	int maxDepth = 0;
+	int maxDepth = 0, wideNeed = 0;
 	ds.n_quads = d->n_quads, ds.n_spheres = d->n_spheres, ds.n_cubes = d->n_cubes, ds.n_planes = d->n_planes, ds.n_tris = d->n_triangles, ds.n_bvh_prims = nbvh;
 	if (nbvh > 0)
 	{
@@ -1605,6 +1729,19 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 		float4* dp = 0, *dq = 0;
 		if (( r = dev_upload( c, &dp, pairs.data(), pairs.size(), &allocs ) ) || ( r = dev_upload( c, &dq, prims.data(), prims.size(), &allocs ) )) return bail( r );
 		ds.pairs = dp, ds.prims = dq;
+		if (c->wide_on && !( ds.root_ref & RT_LEAF ))
+		{
+			std::vector<float4> wide, leafbox;
+			const int need = build_wide_nodes( pairs, ds.root_ref, nbvh, wide, leafbox );
+			if (need >= 0 && need <= 56) // (the per-lane stack lives in LDS; a tree that would need more keeps the pairs)
+			{
+				float4* dw = 0, *dl = 0;
+				if (( r = dev_upload( c, &dw, wide.data(), wide.size(), &allocs ) ) || ( r = dev_upload( c, &dl, leafbox.data(), leafbox.size(), &allocs ) )) return bail( r );
+				ds.wide = dw, ds.leafbox = dl, ds.wide_root = 0;
+				wideNeed = need;
+				if (c->log_bounces) fprintf( stderr, "rtmi: %zu 4-wide nodes over %d pairs, stack need %d (pairs: %d)\n", wide.size() / 4, npairs, need, maxDepth );
+			}
+		}
 	}
 	else ds.root_ref = RT_DONE;
 	// analytic primitives
@@ -1664,11 +1801,12 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	free_batches( c ); // the suspend records are sized by the stack depth
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
+	c->walk_depth = std::max( c->stack_depth, wideNeed + 1 );
 	{
 		// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 4 (16 waves per CU).  The walk is bound by
 		// the memory system's random-access throughput, not by latency: measured on the 1M-triangle scene, 4 blocks per CU
 		// run the walks 8 % faster than 6 (fewer rays in flight share each XCD's 4 MiB L2), 3 as fast as 4, 2 as slow as 6.
-		const size_t per_block = (size_t)c->stack_depth * BLOCK * sizeof( uint32_t );
+		const size_t per_block = (size_t)c->walk_depth * BLOCK * sizeof( uint32_t );
 		int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 4, ( 160 * 1024 ) / per_block ) );
 		const char* e = getenv( "RTMI_BLOCKS_PER_CU" );
 		if (e && atoi( e ) >= 1) per_cu = (int)std::min<size_t>( atoi( e ), std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) ) );
@@ -1717,7 +1855,7 @@ static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)
 
 static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t upper, int budget )
 {
-	const size_t lds = stack_bytes( c );
+	const size_t lds = (size_t)c->walk_depth * BLOCK * sizeof( uint32_t );
 	hipStream_t s = c->stream;
 	DevCounters* ctr = b.ctr;
 	TraceArgs a = {};

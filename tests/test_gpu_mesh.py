@@ -162,6 +162,22 @@ def test_full_size_image_and_properties(full):
     d1.render(api.PATHTRACING, 0, 4, 1)
     assert np.array_equal(bits(d1.accumulator()), bits(four))
     d1.close()
+    # interior nodes: k_trace walks 4-wide nodes with quantised boxes and confirms every hit against the exact box of its
+    # leaf; RTMI_WIDE=0 walks the reference's own boxes (the pairs).  Same hits, same image, bit for bit
+    os.environ["RTMI_WIDE"] = "0"
+    try:
+        d2 = api.Device(W, H)
+    finally:
+        del os.environ["RTMI_WIDE"]
+    d2.upload(scene.desc)
+    d2.set_seeds(seeds)
+    d2.set_camera(api.default_camera(W, H, scene.scale))
+    d2.render(api.PATHTRACING, 0, 4, 1)
+    assert np.array_equal(bits(d2.accumulator()), bits(four))
+    obj2, t2 = d2.trace_primary()
+    obj1, t1 = d.trace_primary()
+    assert np.array_equal(obj1, obj2) and np.array_equal(bits(t1), bits(t2))
+    d2.close()
     # progressive reads: reading the image between renders (late sums are folded at every read) changes rounding only
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 1)
