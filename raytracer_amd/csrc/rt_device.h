@@ -346,10 +346,12 @@ __device__ __forceinline__ uint32_t wide_step( const DScene& s, uint32_t cur, f3
 #pragma unroll
 		for (int j = 0; j < 2; j++)
 		{
-			const float tmin = fmaxf( fmaxf( tnx[j], tny[j] ), tnz[j] ), tmax = fminf( fminf( tfx[j], tfy[j] ), tfz[j] );
-			const bool hit = tmax >= tmin && ( ANY ? tmin < t : tmin <= t ) && tmax > 0 && ref[c + j] != RT_DONE;
-			// order key: entry distance (clamped at 0) with the child number in the two lowest bits
-			key[c + j] = hit ? ( ( __float_as_uint( fmaxf( tmin, 0.0f ) ) & ~3u ) | (uint32_t)( c + j ) ) : 0xFFFFFFFFu;
+			// entry clamped at 0, exit clamped at the ray's t: a superset of tmax >= tmin && tmin <= t && tmax > 0 (it also
+			// lets tmax == 0 and, for ANY, tmin == t through, which these boxes may).  An empty slot has an inverted box and
+			// a harmless reference (the builder), so it needs no test of its own
+			const float tmin = fmaxf( fmaxf( fmaxf( tnx[j], tny[j] ), tnz[j] ), 0.0f ), tmax = fminf( fminf( fminf( tfx[j], tfy[j] ), tfz[j] ), t );
+			// order key: entry distance with the child number in the two lowest bits
+			key[c + j] = tmin <= tmax ? ( ( __float_as_uint( tmin ) & ~3u ) | (uint32_t)( c + j ) ) : 0xFFFFFFFFu;
 		}
 	}
 #define RT_CSWAP( a, b ) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_, key[b] = hi_; }

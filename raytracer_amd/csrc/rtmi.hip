@@ -1597,7 +1597,9 @@ static int build_wide_nodes( const std::vector<float4>& pairs, uint32_t root_pai
 			}
 			ebits |= (uint32_t)e << ( 8 * ax );
 		}
-		uint32_t ref[4] = { RT_DONE, RT_DONE, RT_DONE, RT_DONE };
+		// an empty slot: inverted box (never passes unless rounding collapses it) and the first leaf position as a one-primitive
+		// leaf, so that even then the walk only tests a primitive it would confirm against that leaf's exact box anyway
+		uint32_t ref[4] = { RT_LEAF, RT_LEAF, RT_LEAF, RT_LEAF };
 		for (int i = 0; i < n; i++)
 		{
 			if (ch[i].ref & RT_LEAF)
