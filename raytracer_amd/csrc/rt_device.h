@@ -367,6 +367,34 @@ __device__ __forceinline__ uint32_t wide_step( const DScene& s, uint32_t cur, f3
 #undef RT_PICK
 }
 
+// The whole walk over the 4-wide nodes for one lane (k_tail): the caller has done the root box test and knows that rD is
+// finite.  A hit counts once the exact box of its leaf passes the reference's test (see above).
+template <bool ANY>
+__device__ __forceinline__ bool traverse_wide( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride )
+{
+	uint32_t cur = s.wide_root;
+	int sp = 0;
+	while (true)
+	{
+		while (!( cur & RT_LEAF )) cur = wide_step<ANY>( s, cur, O, rD, h.t, stack, stride, sp );
+		if (cur == RT_DONE) break;
+		const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
+		for (int i = 0; i < count; i++)
+		{
+			const float t0 = h.t;
+			const int obj0 = h.obj, pos0 = h.pos;
+			if (!isect_prim<ANY>( s, first + i, O, D, h )) continue;
+			const float4 b0 = s.leafbox[2 * first], b1 = s.leafbox[2 * first + 1];
+			float tmn, tmx;
+			slab<false>( b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, O, rD, tmn, tmx );
+			if (tmx >= tmn && ( ANY ? tmn < t0 : tmn <= t0 ) && tmx > 0) { if (ANY) return true; }
+			else h.t = t0, h.obj = obj0, h.pos = pos0;
+		}
+		cur = sp > 0 ? stack[--sp * stride] : RT_DONE;
+	}
+	return false;
+}
+
 // Scene::FindNearest (scene.h:359-368): quads[0], cubes[0], planes, BVH.  h.t carries the ray's tmax in.
 template <bool COUNT>
 __device__ __forceinline__ void find_nearest( const DScene& s, f3 O, f3 D, RayHit& h, uint32_t* stack, int stride, TravCount& cnt )

@@ -741,6 +741,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 					if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, per_wave, tc );
+					else if (s.wide) traverse_wide<false>( s, O, D, rD, h, stack, per_wave );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
 				}
 				Vertex v;
@@ -759,7 +760,8 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc );
+						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc )
+							: s.wide ? traverse_wide<true>( s, v.shO, v.shD, rD, sh, stack, per_wave ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc );
 						if (!occ) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
 				}
@@ -1176,8 +1178,8 @@ struct rtmi_ctx
 	bool has_scene = false;
 	DScene ds = {};
 	std::vector<void*> scene_allocs;
-	int stack_depth = 8;         // per-lane traversal stack over the pairs (k_tail, k_whitted, k_trace_rays)
-	int walk_depth = 8;          // same for k_trace: the larger need of the pairs and of the 4-wide nodes; sizes the suspend records
+	int stack_depth = 8;         // per-lane traversal stack over the pairs (k_whitted, k_trace_rays)
+	int walk_depth = 8;          // same for k_trace and k_tail: the larger need of the pairs and of the 4-wide nodes; sizes the suspend records
 	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
 	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
@@ -1327,8 +1329,8 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		const int limit = round == 11 ? 0x7FFFFFFF : len;
 		// waves: enough for the round's upper bound at the density the kernel will choose at most (it reads the live count)
 		const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
-		const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->stack_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
-		const uint32_t lds_words = (uint32_t)c->stack_depth * 64u * wpb;
+		const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->walk_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
+		const uint32_t lds_words = (uint32_t)c->walk_depth * 64u * wpb;
 		hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
 			round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, ctr );
 		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
