@@ -32,9 +32,11 @@ import os
 import sys
 import time
 
-# (librtmi keeps a few render batches in flight, one HIP stream each; since the late paths of a batch ride with the next
-# batches those streams carry milliseconds of work and HIP's default of 4 hardware queues is enough:
-# no GPU_MAX_HW_QUEUES setting is needed, here or under torch.distributed.run.)
+# librtmi uses six HIP streams (the caller's, a side stream for the shadow walks, four for the batch tails).  With HIP's
+# default of 4 hardware queues two of them share a queue and a shadow walk can sit behind a tail round: 8 queues keep them
+# apart (+2 % rays/s; the value must be in the environment before the HIP runtime starts, i.e. before torch is imported).
+if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import numpy as np
 

@@ -875,6 +875,21 @@ __global__ void k_next_bounce( DevCounters* ctr, int consumed, uint32_t* report 
 	if (report) { *report = pending; __threadfence_system(); }
 }
 
+// the same bookkeeping in two parts, for a bounce whose shadow walk runs on the side stream beside the next bounce's
+// closest-hit walk (render_batch): what the next closest-hit walk needs, after k_shade; the rest, after the shadow walk
+__global__ void k_next_bounce_pre( DevCounters* ctr, int consumed )
+{
+	ctr->pool_extend = 0, ctr->n_rec[consumed ^ 1] = 0;
+}
+__global__ void k_next_bounce_post( DevCounters* ctr, int consumed, uint32_t* report )
+{
+	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_connect = 0, ctr->pool_tail = 0;
+	ctr->n_srec[consumed ^ 1] = 0;
+	const uint32_t pending = ctr->n_state[consumed ^ 1] + ctr->n_shadow[consumed ^ 1];
+	ctr->pending = pending;
+	if (report) { *report = pending; __threadfence_system(); }
+}
+
 // ---- accumulate: accumulator[p] += Sample() per sample, in sample order (renderer.cpp:566-567) -------------
 __global__ __launch_bounds__( BLOCK ) void k_accumulate( float4* __restrict__ acc, const float4* __restrict__ E, const long long* __restrict__ Es, int WH, int S )
 {
@@ -1164,6 +1179,7 @@ struct BatchSlot
 	uint32_t* host_counts_dev = 0; // the same ring as the device sees it
 	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
 	hipStream_t tail_stream = 0;
+	hipEvent_t ev_shade = 0, ev_any = 0; // side stream hand-shake (render_batch)
 	PathState left = {};        // late paths that outlived the first round of this batch's k_tail: they join the next batch that uses the slot
 	uint32_t* n_left = 0;
 	hipEvent_t bulk_done = 0, acc_done = 0;
@@ -1180,6 +1196,8 @@ struct rtmi_ctx
 	std::vector<void*> scene_allocs;
 	int stack_depth = 8;         // per-lane traversal stack over the pairs (k_whitted, k_trace_rays)
 	int walk_depth = 8;          // same for k_trace and k_tail: the larger need of the pairs and of the 4-wide nodes; sizes the suspend records
+	hipStream_t side = 0;        // a bounce's shadow walk runs here, beside the next bounce's closest-hit walk on the main stream (RTMI_OVERLAP=0: on the main stream)
+	bool overlap_on = true;
 	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
 	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
@@ -1371,6 +1389,7 @@ static int join_batches( rtmi_ctx* c )
 static int sync_all( rtmi_ctx* c )
 {
 	HIPCHK( hipStreamSynchronize( c->stream ) );
+	if (c->side) HIPCHK( hipStreamSynchronize( c->side ) );
 	for (int k = 0; k < MAX_SLOTS; k++) if (c->slots[k].tail_stream) { HIPCHK( hipStreamSynchronize( c->slots[k].tail_stream ) ); c->slots[k].busy = false; }
 	c->last_acc = 0;
 	return RTMI_OK;
@@ -1401,6 +1420,8 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		// batches in flight: each uses its own stream, and streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES,
 		// 4 unless the process raises it before HIP starts) serialise behind each other
 		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
+		if (getenv( "RTMI_OVERLAP" )) c->overlap_on = atoi( getenv( "RTMI_OVERLAP" ) ) != 0;
+		if (c->overlap_on && hipStreamCreateWithFlags( &c->side, hipStreamNonBlocking ) != hipSuccess) c->overlap_on = false, c->side = 0;
 		if (getenv( "RTMI_WIDE" )) c->wide_on = atoi( getenv( "RTMI_WIDE" ) ) != 0;
 		if (getenv( "RTMI_CARRY" )) c->carry_on = atoi( getenv( "RTMI_CARRY" ) ) != 0;
 		c->n_slots = c->carry_on || !q || atoi( q ) < 7 ? 4 : atoi( q ) >= 13 ? 12 : 6; // whole tails (RTMI_CARRY=0) last 0.5 s: more batches in flight
@@ -1455,6 +1476,7 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		bool ok = hipStreamCreateWithFlags( &b.tail_stream, hipStreamNonBlocking ) == hipSuccess;
 		for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags( &b.count_ev[i], hipEventDisableTiming ) == hipSuccess;
 		ok = ok && hipEventCreateWithFlags( &b.bulk_done, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.acc_done, hipEventDisableTiming ) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags( &b.ev_shade, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.ev_any, hipEventDisableTiming ) == hipSuccess;
 		if (!ok) { rtmi_destroy( c ); return RTMI_ERR_HIP; }
 		(void)hipMemset( b.ctr, 0, sizeof( DevCounters ) );
 		if (dev_alloc( c, &b.left.o_t, c->left_cap ) || dev_alloc( c, &b.left.d_h, c->left_cap ) || dev_alloc( c, &b.left.T_s, c->left_cap ) || dev_alloc( c, &b.left.meta, c->left_cap ) ||
@@ -1489,11 +1511,14 @@ int rtmi_destroy( rtmi_ctx* c )
 		for (int i = 0; i < 4; i++) if (b.count_ev[i]) (void)hipEventDestroy( b.count_ev[i] );
 		if (b.bulk_done) (void)hipEventDestroy( b.bulk_done );
 		if (b.acc_done) (void)hipEventDestroy( b.acc_done );
+		if (b.ev_shade) (void)hipEventDestroy( b.ev_shade );
+		if (b.ev_any) (void)hipEventDestroy( b.ev_any );
 		if (b.tail_stream) (void)hipStreamDestroy( b.tail_stream );
 	}
 	if (c->draining) (void)hipHostFree( c->draining );
 	for (auto e : c->ev_pool) (void)hipEventDestroy( e );
 	if (c->own_stream) (void)hipStreamDestroy( c->own_stream );
+	if (c->side) (void)hipStreamDestroy( c->side );
 	delete c;
 	return RTMI_OK;
 }
@@ -1857,10 +1882,10 @@ static inline int nsblocks( rtmi_ctx* c, size_t n ) { return (int)( ( n + c->sbl
 // persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need
 static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); }
 
-static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t upper, int budget )
+static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t upper, int budget, hipStream_t on = 0 )
 {
 	const size_t lds = (size_t)c->walk_depth * BLOCK * sizeof( uint32_t );
-	hipStream_t s = c->stream;
+	hipStream_t s = on ? on : c->stream;
 	DevCounters* ctr = b.ctr;
 	TraceArgs a = {};
 	a.st = b.st[set], a.sq = b.sq[set], a.sq_out = b.sq[set ^ 1], a.sinks = make_sinks( c, b ), a.wq = b.wq[set];
@@ -1870,7 +1895,7 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	a.n_rec_out = any ? &ctr->n_srec[set] : &ctr->n_rec[set], a.n_rec_in = any ? &ctr->n_srec[set ^ 1] : &ctr->n_rec[set ^ 1];
 	a.n_shadow_out = &ctr->n_shadow[set ^ 1];
 	a.rec_cap = b.rec_cap, a.rec_stride = b.rec_stride, a.refill = c->refill, a.budget = budget;
-	ScopedTimer t( c, any ? 2 : 0 );
+	ScopedTimer t( c, any ? 2 : 0, s );
 	if (any)
 	{
 		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
@@ -1924,7 +1949,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	}
 	int cur = 0;        // state / shadow queue set of this bounce
 	int clean = 0;      // consecutive bounces launched without parking
-	bool tail = false;
+	bool tail = false, side_busy = false;
 	const int min_bounce = c->carry_on && !last ? c->carry_bounce : 0; // with carry, a batch that is still large stays in the loop until its paths are late
 	const uint32_t tail_paths = last ? c->small_paths : c->tail_paths;
 	for (int bounce = 0;; bounce++)
@@ -1939,18 +1964,35 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		const int budget = prep ? 0 : c->budget;
 		clean = prep ? clean + 1 : 0;
 		launch_trace( c, b, false, cur, upper, budget );
+		if (side_busy) { HIPCHK( hipStreamWaitEvent( s, b.ev_any, 0 ) ); side_busy = false; } // the previous bounce's shadow walk fills the queue k_shade appends to
 		{
 			ScopedTimer t( c, 1 );
 			hipLaunchKernelGGL( k_shade, dim3( nsblocks( c, upper ) ), dim3( c->sblock ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], make_sinks( c, b ), &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
 				b.wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
-		launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
 		// what the next bounce starts with (paths + carried shadow rays) goes to pinned host memory; it is looked at two
 		// iterations later
 		const int slot = bounce & 3;
-		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, b.host_counts_dev + slot );
+		if (c->overlap_on)
+		{
+			// this bounce's shadow walk and the next bounce's closest-hit walk need nothing from each other: the shadow walk goes
+			// to the side stream, and as its waves run dry the blocks of the closest-hit walk take their place
+			HIPCHK( hipEventRecord( b.ev_shade, s ) );
+			HIPCHK( hipStreamWaitEvent( c->side, b.ev_shade, 0 ) );
+			launch_trace( c, b, true, cur, upper, budget, c->side );
+			hipLaunchKernelGGL( k_next_bounce_post, dim3( 1 ), dim3( 1 ), 0, c->side, ctr, cur, b.host_counts_dev + slot );
+			HIPCHK( hipEventRecord( b.count_ev[slot], c->side ) );
+			HIPCHK( hipEventRecord( b.ev_any, c->side ) );
+			side_busy = true;
+			hipLaunchKernelGGL( k_next_bounce_pre, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
+		}
+		else
+		{
+			launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
+			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, b.host_counts_dev + slot );
+			HIPCHK( hipEventRecord( b.count_ev[slot], s ) );
+		}
 		c->stats.bounce_launches++;
-		HIPCHK( hipEventRecord( b.count_ev[slot], s ) );
 		cur ^= 1;
 		if (bounce >= 2)
 		{
@@ -1961,6 +2003,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		}
 		if (upper == 0) break;
 	}
+	if (side_busy) { HIPCHK( hipStreamWaitEvent( s, b.ev_any, 0 ) ); side_busy = false; }
 	if (tail && c->carry_on && !last)
 	{
 		// late paths -> carry buffer (they join the next batch, or join_batches finishes them); the others -> the other state set
