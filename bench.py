@@ -21,7 +21,9 @@ achieved = algorithmic bytes of all its launches in the timed region / their sum
 recorded on the stream the kernels run on (inside librtmi, rtmi_set_profiling), i.e. bytes per launch / mean launch
 duration.  Algorithmic bytes per walked ray = 64 B x node-pair records fetched + 48 B x leaf primitive records tested
 + 44 B of ray state (32 B read, 4 B walk index, 8 B hit write); the per-walker record counts
-come from a counting pass of the same kernels over the first step's samples.
+come from a counting pass of the same kernels over the first step's samples.  Since a bounce's k_trace<any> runs beside
+the next bounce's k_trace<closest> (side stream), each launch's duration includes the other's share of the chip;
+roofline.both_walks gives both kernels' algorithmic bytes over the windows they share (k_shade to k_shade).
 
 cpu_baseline: the CPU restatement (oracle/, kind "port"; validated bit-exact against the compiled reference) timed
 on this box's host cores over a bounded row subset of one sample of the same workload.  N=1, rank 0 only.
@@ -165,6 +167,11 @@ def main():
         n_launch = max(1, st["n_extend_launches"])
         achieved = ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
         peak = 8000.0
+        # a bounce's shadow walk shares the chip with the next bounce's closest-hit walk: each launch's
+        # event-timed duration includes the other's share.  Both walks over the windows they share (shade to shade):
+        any_bytes = st["shadow_walkers"] * (64.0 * spairs_per_ray + 48.0 * sprims_per_ray + 48.0)
+        walk_s = st["ms_walk"] * 1e-3
+        pair_achieved = (ext_bytes + any_bytes) / walk_s / 1e9 if walk_s > 0 else None
         out = {
             "metric": "Mrays/s (whole node), path-traced OBJ scene 1080p", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
@@ -181,8 +188,11 @@ def main():
                          "traffic": a.traffic_bytes_per_launch, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
                          "launches": st["n_extend_launches"], "bytes_per_walked_ray": bytes_per_extend_ray, "node_pairs_per_walked_ray": pairs_per_ray,
                          "leaf_prims_per_walked_ray": prims_per_ray, "shadow_node_pairs_per_walked_ray": spairs_per_ray,
-                         "shadow_leaf_prims_per_walked_ray": sprims_per_ray, "longest_walk_steps": [cs["max_extend_steps"], cs["max_shadow_steps"]]},
-            "kernel_ms": {"extend": st["ms_extend"], "shade": st["ms_shade"], "connect": st["ms_connect"], "other": st["ms_other"]},
+                         "shadow_leaf_prims_per_walked_ray": sprims_per_ray, "longest_walk_steps": [cs["max_extend_steps"], cs["max_shadow_steps"]],
+                         "both_walks": {"note": "k_trace<any> of bounce b runs beside k_trace<closest> of bounce b+1; algorithmic bytes of both / time of the windows they share",
+                                        "achieved": pair_achieved, "frac": pair_achieved / peak if pair_achieved else None, "window_ms": st["ms_walk"],
+                                        "windows": st["n_walk_windows"]}},
+            "kernel_ms": {"extend": st["ms_extend"], "shade": st["ms_shade"], "connect": st["ms_connect"], "other": st["ms_other"], "walk_windows": st["ms_walk"]},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, seeds, a.cpu_seconds)

@@ -100,6 +100,9 @@ typedef struct rtmi_stats {
 	uint64_t shadow_walkers;    /* same for any-hit rays */
 	uint64_t suspended;         /* walks parked at the end of a launch and resumed in the next bounce (tail control) */
 	uint64_t max_extend_steps, max_shadow_steps; /* longest single walk in steps (pairs + leaf records); count_nodes only */
+	double   ms_walk;           /* hipEvent time between consecutive shade launches: a bounce's shadow walk and the next bounce's closest-hit walk
+	                               share the chip in it (profiling mode only); ms_extend / ms_connect each span their own launch and overlap */
+	uint64_t n_walk_windows;
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,

@@ -88,7 +88,8 @@ class Stats(C.Structure):
                 ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_connect", C.c_double), ("ms_other", C.c_double),
                 ("n_extend_launches", C.c_uint64), ("n_shade_launches", C.c_uint64), ("n_connect_launches", C.c_uint64),
                 ("extend_walkers", C.c_uint64), ("shadow_walkers", C.c_uint64),
-                ("suspended", C.c_uint64), ("max_extend_steps", C.c_uint64), ("max_shadow_steps", C.c_uint64)]
+                ("suspended", C.c_uint64), ("max_extend_steps", C.c_uint64), ("max_shadow_steps", C.c_uint64),
+                ("ms_walk", C.c_double), ("n_walk_windows", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

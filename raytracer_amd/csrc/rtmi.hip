@@ -1290,6 +1290,7 @@ static void resolve_timers( rtmi_ctx* c )
 			if (t.cls == 0) c->stats.ms_extend += ms, c->stats.n_extend_launches++;
 			else if (t.cls == 1) c->stats.ms_shade += ms, c->stats.n_shade_launches++;
 			else if (t.cls == 2) c->stats.ms_connect += ms, c->stats.n_connect_launches++;
+			else if (t.cls == 4) c->stats.ms_walk += ms, c->stats.n_walk_windows++;
 			else c->stats.ms_other += ms;
 		}
 		c->ev_pool.push_back( t.a ), c->ev_pool.push_back( t.b );
@@ -1950,6 +1951,8 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	int cur = 0;        // state / shadow queue set of this bounce
 	int clean = 0;      // consecutive bounces launched without parking
 	bool tail = false, side_busy = false;
+	hipEvent_t window = 0; // (profiling) open walk window: from the end of a k_shade to the point where both walks after it are done
+	auto close_window = [&]() { if (window) { hipEvent_t e = get_event( c ); (void)hipEventRecord( e, s ); c->timed.push_back( { window, e, 4 } ); window = 0; } };
 	const int min_bounce = c->carry_on && !last ? c->carry_bounce : 0; // with carry, a batch that is still large stays in the loop until its paths are late
 	const uint32_t tail_paths = last ? c->small_paths : c->tail_paths;
 	for (int bounce = 0;; bounce++)
@@ -1963,8 +1966,10 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		if (tail_paths && clean >= 1 && ( ( upper <= tail_paths && bounce >= min_bounce ) || upper <= c->small_paths )) { tail = true; break; }
 		const int budget = prep ? 0 : c->budget;
 		clean = prep ? clean + 1 : 0;
+		if (bounce == 0 && c->overlap_on && c->prof_events) { window = get_event( c ); (void)hipEventRecord( window, s ); } // the first walk has a window to itself
 		launch_trace( c, b, false, cur, upper, budget );
 		if (side_busy) { HIPCHK( hipStreamWaitEvent( s, b.ev_any, 0 ) ); side_busy = false; } // the previous bounce's shadow walk fills the queue k_shade appends to
+		close_window();
 		{
 			ScopedTimer t( c, 1 );
 			hipLaunchKernelGGL( k_shade, dim3( nsblocks( c, upper ) ), dim3( c->sblock ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], make_sinks( c, b ), &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
@@ -1985,6 +1990,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			HIPCHK( hipEventRecord( b.ev_any, c->side ) );
 			side_busy = true;
 			hipLaunchKernelGGL( k_next_bounce_pre, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
+			if (c->prof_events) { window = get_event( c ); (void)hipEventRecord( window, s ); }
 		}
 		else
 		{
@@ -2004,6 +2010,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		if (upper == 0) break;
 	}
 	if (side_busy) { HIPCHK( hipStreamWaitEvent( s, b.ev_any, 0 ) ); side_busy = false; }
+	close_window();
 	if (tail && c->carry_on && !last)
 	{
 		// late paths -> carry buffer (they join the next batch, or join_batches finishes them); the others -> the other state set
