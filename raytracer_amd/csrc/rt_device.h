@@ -95,6 +95,7 @@ struct DScene
 	const uint32_t* __restrict__ texture;
 	int tex_w, tex_h;
 	float4 light_c1, light_c2, light_c3, light_emission, light_N;
+	float4 light_u, light_w; // normalize(c1 - c2), normalize(c3 - c2): the same for every sample, computed once on upload with the same operations
 	float light_A, light_s;
 	float4 wl_pos[2], wl_color[2];
 	float wl_intensity;

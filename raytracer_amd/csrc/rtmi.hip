@@ -545,11 +545,11 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 	{
 		const f3 BRDF = a.albedo / 3.14159265358979323846264f;
 		// Scene::RandomPointOnLight, scene.h:317-341
-		const f3 c1 = mk3( s.light_c1 ), c2 = mk3( s.light_c2 ), c3 = mk3( s.light_c3 ), Nl = mk3( s.light_N );
-		const f3 c1c2 = normalize3( c1 - c2 );
+		const f3 c2 = mk3( s.light_c2 ), Nl = mk3( s.light_N );
+		const f3 c1c2 = mk3( s.light_u ); // normalize( c1 - c2 ), rtmi_upload_scene
 		float len = rng_float( rng ) * s.light_s;
 		const f3 u = c1c2 * len;
-		const f3 c2c3 = normalize3( c3 - c2 );
+		const f3 c2c3 = mk3( s.light_w ); // normalize( c3 - c2 )
 		len = rng_float( rng ) * s.light_s;
 		const f3 w = c2c3 * len;
 		const f3 lp = c2 + u + w - mk3( 0, 0.01f, 0 );
@@ -1822,6 +1822,16 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	}
 	memcpy( &ds.light_c1, d->light_corners, 16 ), memcpy( &ds.light_c2, d->light_corners + 4, 16 ), memcpy( &ds.light_c3, d->light_corners + 8, 16 );
 	memcpy( &ds.light_emission, d->light_emission, 16 );
+	{
+		// Scene::RandomPointOnLight normalises the two edge vectors of the light for every sample (scene.h:319, 326); they do
+		// not depend on the sample.  Same binary32 operations in the same order as normalize3 in rt_device.h (this file is
+		// compiled with -ffp-contract=off for the host too; x86-64 sqrtss / divss round correctly like the device's)
+		auto unit = []( const float4& a, const float4& b ) {
+			const float x = a.x - b.x, y = a.y - b.y, z = a.z - b.z;
+			const float inv = 1.0f / sqrtf( x * x + y * y + z * z );
+			return make_float4( x * inv, y * inv, z * inv, 0 ); };
+		ds.light_u = unit( ds.light_c1, ds.light_c2 ), ds.light_w = unit( ds.light_c3, ds.light_c2 );
+	}
 	if (d->n_quads > 0) memcpy( &ds.light_N, d->primitives, 16 ); // quads[0].N, scene.h:120 / 323
 	ds.light_A = d->light_A, ds.light_s = d->light_s;
 	memcpy( ds.wl_pos, d->whitted_light_pos, 32 ), memcpy( ds.wl_color, d->whitted_light_color, 32 );
