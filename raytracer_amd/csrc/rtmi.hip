@@ -4,12 +4,15 @@
 //   k_primary           ray generation: camera ray, per-(pixel, sample) rng state, analytic part of FindNearest,
 //                       root box test                                                      (camera.h:28-35, scene.h:359-368)
 //   per bounce:
-//   k_trace<closest>    persistent waves walk the BVH for the rays that entered its root box (bvh.h:507-530)
+//   k_trace<closest>    persistent waves walk the BVH for the rays that entered its root box (bvh.h:507-530): 4-wide nodes
+//                       with quantised boxes built on upload, every hit confirmed against the exact box of its leaf
+//                       (rt_device.h: wide_step); rays with an infinite reciprocal direction walk the reference's pairs
 //   k_shade             material evaluation, NEE, Russian roulette (renderer.cpp:246-365); CREATES the next ray and the
 //                       shadow ray and runs their analytic intersections + root box tests; survivors are written in
 //                       queue order to the other state set, BVH walkers are appended to the walk / shadow queues with
 //                       one atomic per 1024-thread block (ballot + mbcnt prefix per wave, LDS scan across waves)
-//   k_trace<any>        any-hit walk of the shadow queue, E[slot] += contribution          (scene.h:369-379, renderer.cpp:339-344)
+//   k_trace<any>        any-hit walk of the shadow queue, E[slot] += contribution          (scene.h:369-379, renderer.cpp:339-344);
+//                       on a side stream, beside the next bounce's k_trace<closest> (render_batch)
 //   k_carry_out / _in   the paths still alive when a batch leaves the bounce loop are late (>= 15 vertices: they add to an
 //                       exact per-pixel sum, see Sinks) and join the next batch's queue; k_tail runs what is left of a
 //                       render's paths to their ends when the caller reads the image

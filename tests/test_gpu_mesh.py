@@ -178,6 +178,19 @@ def test_full_size_image_and_properties(full):
     obj1, t1 = d.trace_primary()
     assert np.array_equal(obj1, obj2) and np.array_equal(bits(t1), bits(t2))
     d2.close()
+    # streams: a bounce's shadow walk runs on a side stream beside the next bounce's closest-hit walk; RTMI_OVERLAP=0 runs
+    # them one after the other on the caller's stream.  Same bits
+    os.environ["RTMI_OVERLAP"] = "0"
+    try:
+        d3 = api.Device(W, H)
+    finally:
+        del os.environ["RTMI_OVERLAP"]
+    d3.upload(scene.desc)
+    d3.set_seeds(seeds)
+    d3.set_camera(api.default_camera(W, H, scene.scale))
+    d3.render(api.PATHTRACING, 0, 4, 1)
+    assert np.array_equal(bits(d3.accumulator()), bits(four))
+    d3.close()
     # progressive reads: reading the image between renders (late sums are folded at every read) changes rounding only
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 1)
