@@ -1204,6 +1204,7 @@ struct rtmi_ctx
 	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
 	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
+	uint32_t grid_closest[2] = { 0, 0 }, grid_any[2] = { 0, 0 }; // wgrid; RTMI_GRID_CLOSEST / RTMI_GRID_ANY "a,b" (paths) override, "0,0": always 4 blocks per CU
 	int n_cus = 256;
 	CamProp cam = {};
 	uint32_t* seeds = 0;
@@ -1426,6 +1427,12 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
 		if (getenv( "RTMI_OVERLAP" )) c->overlap_on = atoi( getenv( "RTMI_OVERLAP" ) ) != 0;
 		if (c->overlap_on && hipStreamCreateWithFlags( &c->side, hipStreamNonBlocking ) != hipSuccess) c->overlap_on = false, c->side = 0;
+		{
+			const uint32_t lanes = (uint32_t)c->n_cus * 1024u; // 4 blocks of 256 per CU
+			c->grid_closest[0] = 61u * lanes, c->grid_closest[1] = 19u * lanes, c->grid_any[0] = 76u * lanes, c->grid_any[1] = 30u * lanes;
+		}
+		if (getenv( "RTMI_GRID_CLOSEST" )) sscanf( getenv( "RTMI_GRID_CLOSEST" ), "%u,%u", &c->grid_closest[0], &c->grid_closest[1] );
+		if (getenv( "RTMI_GRID_ANY" )) sscanf( getenv( "RTMI_GRID_ANY" ), "%u,%u", &c->grid_any[0], &c->grid_any[1] );
 		if (getenv( "RTMI_WIDE" )) c->wide_on = atoi( getenv( "RTMI_WIDE" ) ) != 0;
 		if (getenv( "RTMI_CARRY" )) c->carry_on = atoi( getenv( "RTMI_CARRY" ) ) != 0;
 		c->n_slots = c->carry_on || !q || atoi( q ) < 7 ? 4 : atoi( q ) >= 13 ? 12 : 6; // whole tails (RTMI_CARRY=0) last 0.5 s: more batches in flight
@@ -1893,8 +1900,20 @@ int rtmi_set_accumulator( rtmi_ctx* c, void* p )
 static size_t stack_bytes( rtmi_ctx* c ) { return (size_t)c->stack_depth * BLOCK * sizeof( uint32_t ); }
 
 static inline int nsblocks( rtmi_ctx* c, size_t n ) { return (int)( ( n + c->sblock - 1 ) / c->sblock ); }
-// persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need
-static inline dim3 pgrid( rtmi_ctx* c, uint32_t rays ) { return dim3( (unsigned)std::max( 1, std::min( nblocks( rays ), c->max_blocks ) ) ); }
+// persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need.
+// the walks: fewer resident blocks per CU once a bounce is small (`upper` = the bounce's path count bound; the rays that
+// walk are a sixth to a tenth of it).  A small launch is a chain of dependent fetches per wave, and each wave's chain runs
+// faster with fewer waves beside it on its SIMD; a large one needs all the lanes it can get.  Measured per launch on the
+// bench scene (sequential streams, us, 4 / 3 / 2 blocks per CU): closest-hit walk of bounce 2: 1683 / 1892 / 2539, of bounce
+// 16: 268 / 246 / 256; shadow walk of bounce 8: 340 / 312 / 314, of bounce 16: 226 / 203 / 163.  With the shadow walk on the
+// side stream (render_batch) two small walks also fit a CU together.  Thresholds in paths per resident lane, set in rtmi_create.
+static inline dim3 wgrid( rtmi_ctx* c, bool any, uint32_t upper )
+{
+	const uint32_t* lim = any ? c->grid_any : c->grid_closest; // path counts below which a launch gets 3, then 2 blocks per CU
+	const int per_cu = upper < lim[1] ? 2 : upper < lim[0] ? 3 : 4;
+	const int blocks = std::min( c->max_blocks, c->n_cus * per_cu );
+	return dim3( (unsigned)std::max( 1, std::min( nblocks( upper ), blocks ) ) );
+}
 
 static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t upper, int budget, hipStream_t on = 0 )
 {
@@ -1912,13 +1931,13 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	ScopedTimer t( c, any ? 2 : 0, s );
 	if (any)
 	{
-		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<true, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-		else hipLaunchKernelGGL( ( k_trace<true, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<true, true> ), wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		else hipLaunchKernelGGL( ( k_trace<true, false> ), wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 	else
 	{
-		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<false, true> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-		else hipLaunchKernelGGL( ( k_trace<false, false> ), pgrid( c, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		if (c->count_nodes) hipLaunchKernelGGL( ( k_trace<false, true> ), wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		else hipLaunchKernelGGL( ( k_trace<false, false> ), wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 }
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
