@@ -1219,11 +1219,11 @@ struct rtmi_ctx
 	long long* late = 0;         // 4 x int64 per pixel
 	PathState carry[2] = {};     // [0] collects (k_carry_out) and feeds (k_carry_in); [1] is the ping-pong partner of the final tail
 	DevCounters* carry_ctr = 0;  // n_state[0] = paths in carry[0]
-	uint32_t carry_cap = 1u << 22, left_cap = 1u << 16;
+	uint32_t carry_cap = 1u << 23, left_cap = 1u << 16;
 	bool carry_on = true;        // RTMI_CARRY=0: every batch finishes all of its paths in its own tail
 	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
 	uint32_t small_paths = 1u << 18; // a batch with no more paths than this leaves the wavefront loop at once
-	int carry_bounce = 17;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
+	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
 	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
@@ -1450,7 +1450,7 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		if (e && atoll( e ) >= 0) c->tail_mid = (uint32_t)atoll( e );
 		e = getenv( "RTMI_SLOTS" );
 		if (e && atoi( e ) >= 1 && atoi( e ) <= MAX_SLOTS) c->n_slots = atoi( e );
-		c->tail_paths = c->carry_on ? 1u << 21 : c->small_paths;
+		c->tail_paths = c->carry_on ? 1u << 22 : c->small_paths;
 		e = getenv( "RTMI_TAIL_PATHS" );
 		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );
 		e = getenv( "RTMI_CARRY_CAP" ); // (tests: small buffers exercise the paths taken when they are full)
