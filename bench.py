@@ -60,23 +60,39 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
                     help="HBM bytes per k_trace<closest> launch; default: the committed result of the separate rocprofv3 --pmc "
-                         "passes (profiles/r01_traffic.json, tools/profile_gpu.sh + tools/traffic.py), null if absent")
+                         "passes (profiles/rNN_traffic.json, tools/profile_gpu.sh + tools/traffic.py), null if absent")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the headline): every rank renders --spp-per-step samples per step.  strong: a step is ONE frame of "
+                         "--total-spp samples split by index over the ranks (BASELINE.json configs[3]: 256 spp at 3840x2160 over 2/4/8 GPUs)")
+    ap.add_argument("--total-spp", type=int, default=256, help="--scaling strong: samples per pixel per step, all ranks together")
+    ap.add_argument("--share-of", type=int, default=1,
+                    help="single process only: render the share of rank 0 of this many ranks (sample indices 0, N, 2N, ...), i.e. what ONE GPU of an "
+                         "N-GPU run does between the start and the reduce; the JSON line is then a per-rank rehearsal, not a whole-node figure")
+    ap.add_argument("--reduce", choices=["torch", "rtmi"], default="torch",
+                    help="who sums the accumulators: torch.distributed (default) or rtmi_reduce_accumulator on an RCCL communicator of its own")
     return ap.parse_args()
 
 
-def committed_traffic():
-    """PMC counters cannot be collected inside this run (rocprofv3 --pmc is its own pass); use the committed figure."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return float(json.load(f)["kernels"]["k_trace<closest>"]["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+def committed_pmc():
+    """PMC counters cannot be collected inside this run (rocprofv3 --pmc is its own pass per counter group): the figures of the
+    committed passes of the same command (tools/profile_gpu.sh -> tools/traffic.py), newest round first.  Returns (dict, file)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                k = json.load(f)["kernels"]["k_trace<closest>"]
+            return k, "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
 
 
 def main():
     a = parse()
-    if a.traffic_bytes_per_launch is None:
-        a.traffic_bytes_per_launch = committed_traffic()
+    pmc, pmc_file = committed_pmc()
+    traffic_source = "--traffic-bytes-per-launch" if a.traffic_bytes_per_launch is not None else None
+    if a.traffic_bytes_per_launch is None and "traffic_bytes_per_launch" in pmc:
+        a.traffic_bytes_per_launch = float(pmc["traffic_bytes_per_launch"])
+        traffic_source = "%s: separate rocprofv3 --pmc passes of an earlier run of this command (%s), not this run" % (pmc_file, pmc.get("command", "bench.py --steps 3"))
     import torch
     import torch.distributed as dist
     from raytracer_amd import api
@@ -106,15 +122,30 @@ def main():
     dev.set_camera(api.default_camera(W, H, scene.scale))
     seeds = api.seed_table(W * H)
     dev.set_seeds(seeds)
+    # Everything below runs on ONE explicit torch stream: the library enqueues on it (rtmi_set_stream takes the stream as it
+    # is), rtmi_flush makes it wait for the library's internal streams, and the collective -- issued while it is torch's current
+    # stream -- is ordered after it by torch's own event.  (On torch's default stream the handle would get the null stream;
+    # that works too, but a named stream keeps the ordering explicit and independent of null-stream semantics.)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream()
     dev.set_stream(stream.cuda_stream)
     dev.set_accumulator(acc.data_ptr())
+    strong = a.scaling == "strong"
+    share = max(1, a.share_of)
+    if share > 1 and world > 1:
+        raise SystemExit("--share-of is a single-process rehearsal")
+    v_world, v_rank = (share, 0) if share > 1 else (world, rank)  # the split this process renders its part of
+    # samples per step over all (virtual) ranks: weak = spp-per-step each, strong = one frame of total-spp
+    step_spp = a.total_spp if strong else a.spp_per_step * v_world
     spp = a.spp_per_step
+    comm = None
+    if a.reduce == "rtmi" and use_dist:
+        comm = rccl_communicator(dist, rank, world, local_rank)
 
     def step(i):
-        # step i covers the global sample indices [i*spp*world, (i+1)*spp*world); this rank renders every world-th one
-        D.render_split(lambda b, n, st: dev.render(api.PATHTRACING, b, n, st), i * spp * world, spp * world, rank, world)
+        # step i covers the global sample indices [i*step_spp, (i+1)*step_spp); this rank renders every v_world-th one
+        D.render_split(lambda b, n, st: dev.render(api.PATHTRACING, b, n, st), i * step_spp, step_spp, v_rank, v_world)
 
     def barrier():
         if use_dist:
@@ -144,21 +175,25 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
-    dev.flush()  # the tails of the last batches run on the library's own streams: order the reduce after them
-    D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once (no-op for one rank)
-    pixels = dev.finalize(a.steps * spp * world) if rank == 0 else None
+    if comm is not None:
+        dev.reduce_accumulator(comm, 0)  # inside the boundary: finishes the paths in flight, then one ncclReduce on the handle's stream
+    else:
+        dev.flush()  # the tails of the last batches run on the library's own streams: order the reduce after them
+        D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once (no-op for one rank)
+    pixels = dev.finalize(a.steps * step_spp) if rank == 0 else None
     barrier()
     dt = time.perf_counter() - t0
     st = dev.stats()
     dev.set_profiling(False, False)
 
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([st["extend_rays"] + st["shadow_rays"], st["extend_rays"], st["shadow_rays"], st["primary_samples"]], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([st["extend_rays"] + st["shadow_rays"], st["extend_rays"], st["shadow_rays"], st["primary_samples"],
+                         st["extend_walkers"] + st["shadow_walkers"]], dtype=torch.float64, device="cuda")
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     dt = float(tt.item())
-    total_rays, ext_rays, sh_rays, paths = [float(x) for x in rays.tolist()]
+    total_rays, ext_rays, sh_rays, paths, walked = [float(x) for x in rays.tolist()]
 
     if rank == 0:
         bytes_per_extend_ray = 64.0 * pairs_per_ray + 48.0 * prims_per_ray + 44.0  # per ray that walks the BVH
@@ -172,20 +207,31 @@ def main():
         any_bytes = st["shadow_walkers"] * (64.0 * spairs_per_ray + 48.0 * sprims_per_ray + 48.0)
         walk_s = st["ms_walk"] * 1e-3
         pair_achieved = (ext_bytes + any_bytes) / walk_s / 1e9 if walk_s > 0 else None
+        cfg = "configs[3]" if strong and (W, H) == (3840, 2160) else "configs[2]"
+        per = ("one frame of %d spp per step split over the ranks" % a.total_spp) if strong else ("%d spp per step per GPU" % spp)
         out = {
             "metric": "Mrays/s (whole node), path-traced OBJ scene 1080p", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: path-traced torus-knot scene (diffuse, mirror, glass) in the reference room built in %gx units, %d triangles, "
-                                   "%dx%d, %d spp per step per GPU, samples split by index over ranks, one RCCL reduce + RGB8 finalize at the end"
-                                   % (scene.scale, info["triangles"], W, H, spp), "scene_scale": scene.scale,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: path-traced torus-knot scene (diffuse, mirror, glass) in the reference room built in %gx units, %d triangles, "
+                                   "%dx%d, %s, samples split by index over ranks, one RCCL reduce + RGB8 finalize at the end"
+                                   % (cfg, scene.scale, info["triangles"], W, H, per), "scene_scale": scene.scale,
                        "triangles": info["triangles"], "bvh_nodes": info["nodes_used"], "bvh_depth": info["max_depth"], "builder": a.builder,
-                       "width": W, "height": H, "spp_per_step": spp, "total_spp": a.steps * spp * world, "parallelism": "sample-split x%d" % world},
+                       "width": W, "height": H, "spp_per_step": step_spp // v_world, "total_spp": a.steps * step_spp, "parallelism": "sample-split x%d" % world,
+                       "reduce": a.reduce},
             "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays,
             "extend_walkers": float(st["extend_walkers"]), "shadow_walkers": float(st["shadow_walkers"]), "rays_per_path": total_rays / max(1.0, paths),
+            # what the headline counts: every closest-hit and any-hit ray.  Most of them end on the room's analytic primitives inside
+            # the kernel that created them; the rays that enter the BVH's root box and walk the tree (rank 0's counters):
+            "walked_mrays_per_s": walked / dt / 1e6,
+            "extend_walk_fraction": float(st["extend_walkers"]) / max(1.0, float(st["extend_rays"])),
+            "shadow_walk_fraction": float(st["shadow_walkers"]) / max(1.0, float(st["shadow_rays"])),
+            # host time from rtmi_flush to the return of rtmi_finalize: the last paths of the render (+ reduce and finalize)
+            "drain_ms": st["ms_drain"],
+            "l2_hit_rate": pmc.get("l2_hit_rate"), "l2_hit_rate_source": pmc_file,
             "scene_build_s": build_s,
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": a.traffic_bytes_per_launch, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
+                         "traffic": a.traffic_bytes_per_launch, "traffic_source": traffic_source, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
                          "launches": st["n_extend_launches"], "bytes_per_walked_ray": bytes_per_extend_ray, "node_pairs_per_walked_ray": pairs_per_ray,
                          "leaf_prims_per_walked_ray": prims_per_ray, "shadow_node_pairs_per_walked_ray": spairs_per_ray,
                          "shadow_leaf_prims_per_walked_ray": sprims_per_ray, "longest_walk_steps": [cs["max_extend_steps"], cs["max_shadow_steps"]],
@@ -194,12 +240,46 @@ def main():
                                         "windows": st["n_walk_windows"]}},
             "kernel_ms": {"extend": st["ms_extend"], "shade": st["ms_shade"], "connect": st["ms_connect"], "other": st["ms_other"], "walk_windows": st["ms_walk"]},
         }
+        if share > 1:
+            out["rehearsal"] = "rank 0's share of a %d-rank %s-scaling run, rendered by one process: per-rank time without the reduce; not a whole-node figure" % (share, a.scaling)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, seeds, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rccl_communicator(dist, rank, world, local_rank):
+    """An RCCL communicator of this process's own for rtmi_reduce_accumulator (a C++ host would call ncclCommInitRank the same
+    way): rank 0 makes the unique id, torch.distributed carries its 128 bytes to the others."""
+    import ctypes as C
+    import torch
+    lib = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            lib = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        raise SystemExit("--reduce rtmi: librccl.so.1 not found")
+    uid = (C.c_byte * 128)()
+    if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise SystemExit("ncclGetUniqueId failed")
+    t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device="cuda")
+    dist.broadcast(t, 0)
+    uid = (C.c_byte * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+    comm = C.c_void_p()
+
+    class Uid(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    u = Uid()
+    C.memmove(C.byref(u), uid, 128)
+    if lib.ncclCommInitRank(C.byref(comm), world, u, rank) != 0:
+        raise SystemExit("ncclCommInitRank failed")
+    return comm.value
 
 
 def cpu_baseline(scene, W, H, seeds, budget_s):

@@ -103,14 +103,30 @@ typedef struct rtmi_stats {
 	double   ms_walk;           /* hipEvent time between consecutive shade launches: a bounce's shadow walk and the next bounce's closest-hit walk
 	                               share the chip in it (profiling mode only); ms_extend / ms_connect each span their own launch and overlap */
 	uint64_t n_walk_windows;
+	/* the end-of-render tail kernels, option "tail_profile" only (else 0): lane-summed 100 MHz ticks spent in
+	 * [0] analytic tests of the next ray, [1] closest-hit walk, [2] shading, [3] shadow ray (analytic + walk), and
+	 * [4] path-bounces, [5] node steps, [6] leaf primitive tests, [7] wave-ticks of the whole rounds */
+	uint64_t tail_profile[8];
+	double   ms_drain;          /* host time spent inside the read-back / flush calls waiting for the last paths (always measured) */
+	uint64_t n_drains;
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,
  * template.cpp:1513-1665).  One handle = one GPU (`device_id` is the HIP ordinal). */
 int rtmi_create( rtmi_ctx** out, int device_id, int width, int height );
 int rtmi_destroy( rtmi_ctx* );
-/* Run on a caller-owned HIP stream (a torch stream's cuda_stream) instead of the handle's own.  NULL restores it. */
+/* Run on a caller-owned HIP stream (a torch stream's cuda_stream) instead of the handle's own.  The value is taken as
+ * it is: NULL is HIP's null (legacy default) stream, not "none".  rtmi_use_own_stream goes back to the handle's own
+ * (non-blocking) stream.  Both first wait for everything enqueued so far. */
 int rtmi_set_stream( rtmi_ctx*, void* hip_stream );
+int rtmi_use_own_stream( rtmi_ctx* );
+/* Tuning and diagnostics per handle (the reference has compile-time #defines and ImGui toggles; nothing of
+ * this kind crosses its Kernel/Buffer seam).  Keys are the lower-case names listed in DESIGN.md 3 ("wide", "overlap",
+ * "carry", "batch", "slots", "tail_team", "hook_kernel", "check_launches", ...); an environment variable RTMI_<KEY>
+ * only supplies the default a handle starts with.  Waits for the work in flight; options that size buffers
+ * reallocate them; "wide" takes effect at the next rtmi_upload_scene.  Unknown key or bad value: RTMI_ERR_INVALID. */
+int rtmi_set_option( rtmi_ctx*, const char* key, long long value );
+int rtmi_get_option( rtmi_ctx*, const char* key, long long* value_out );
 
 /* Replaces the first-tick SetArguments + CopyToDevice block (renderer.cpp:453-513).  The library repacks the
  * reference-layout arrays into its own 64-byte-aligned two-child node records and leaf-ordered primitive records. */
@@ -160,6 +176,13 @@ int rtmi_synchronize( rtmi_ctx* );
  * it enqueues that completion and makes the handle's stream wait for everything rendered so far.  The accumulator is
  * the sum of whole samples only after one of these calls. */
 int rtmi_flush( rtmi_ctx* );
+/* Multi-GPU inside the boundary (no reference counterpart: it has one OpenCL context, precomp.h:1544-1546).  Samples are
+ * split by index over one handle per GPU (rtmi_render's sample_begin / sample_stride); this sums the float4[W*H]
+ * accumulators of all ranks of `rccl_comm` (an ncclComm_t created by the caller with ncclCommInitRank / ncclCommInitAll;
+ * librccl is loaded on first use) onto rank `root` with ONE ncclReduce(sum, float) over xGMI, in place, on the handle's
+ * stream, after finishing the paths in flight like rtmi_flush.  root < 0: ncclAllReduce (every rank gets the sum).
+ * Asynchronous like rtmi_render; rtmi_finalize on the root with frames = total samples completes the frame. */
+int rtmi_reduce_accumulator( rtmi_ctx*, void* rccl_comm, int root );
 
 /* Counters and timing (the reference only prints a frame time, renderer.cpp:635-641). */
 int rtmi_set_profiling( rtmi_ctx*, int hip_event_timing, int count_nodes );

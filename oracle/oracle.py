@@ -21,6 +21,7 @@ def lib():
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_sample_seed.restype = C.c_uint32
         L.orc_max_threads.restype = C.c_int
+        L.orc_camera_script.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -196,3 +197,21 @@ class Oracle:
         nodes, prim = np.zeros((2 * n + 1, 8), np.uint32), np.zeros(n, np.int32)
         used = self.L.orc_bvh_build_reference(_p(v9), len(v9), _p(pr4), len(pr4), _p(nodes), _p(prim))
         return nodes[:used], prim
+
+    def camera_script(self, W, H, events):
+        """events: list of ("down"|"up", key) | ("update",) | ("fov", degrees) | ("aspect", ratio); returns (cams[n_updates, 16],
+        moved[n_updates]) -- Camera::Update by Camera::Update (camera.h:95-159, renderer.cpp:368-441)"""
+        kinds = {"down": 0, "up": 1, "update": 2, "fov": 3, "aspect": 4}
+        ev = np.zeros((len(events), 2), np.int32)
+        val = np.zeros(len(events), np.float32)
+        for k, e in enumerate(events):
+            ev[k, 0] = kinds[e[0]]
+            if e[0] in ("down", "up"):
+                ev[k, 1] = e[1]
+            elif e[0] in ("fov", "aspect"):
+                val[k] = e[1]
+        n = sum(1 for e in events if e[0] == "update")
+        cams, moved = np.zeros((max(n, 1), 16), np.float32), np.zeros(max(n, 1), np.int32)
+        got = self.L.orc_camera_script(W, H, len(events), _p(ev), _p(val), _p(cams), _p(moved))
+        assert got == n
+        return cams[:n], moved[:n]

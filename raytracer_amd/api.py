@@ -20,6 +20,8 @@ ASSETS = os.path.join(ROOT, "assets")
 NORMAL, DISTANCE, ALBEDO, RAYTRACING, PATHTRACING = range(5)
 DIFFUSE, MIRROR, GLASS, SUBSTANCE, LIGHT = range(5)
 REFERENCE_SAH, BINNED_SAH = 0, 1
+# GLFW key codes the reference's Renderer::KeyDown / KeyUp handle (renderer.cpp:368-441)
+KEY_A, KEY_D, KEY_E, KEY_Q, KEY_S, KEY_W, KEY_RIGHT, KEY_LEFT, KEY_DOWN, KEY_UP = 65, 68, 69, 81, 83, 87, 262, 263, 264, 265
 
 
 class RtmiError(RuntimeError):
@@ -89,10 +91,11 @@ class Stats(C.Structure):
                 ("n_extend_launches", C.c_uint64), ("n_shade_launches", C.c_uint64), ("n_connect_launches", C.c_uint64),
                 ("extend_walkers", C.c_uint64), ("shadow_walkers", C.c_uint64),
                 ("suspended", C.c_uint64), ("max_extend_steps", C.c_uint64), ("max_shadow_steps", C.c_uint64),
-                ("ms_walk", C.c_double), ("n_walk_windows", C.c_uint64)]
+                ("ms_walk", C.c_double), ("n_walk_windows", C.c_uint64),
+                ("tail_profile", C.c_uint64 * 8), ("ms_drain", C.c_double), ("n_drains", C.c_uint64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k == "tail_profile" else getattr(self, k)) for k, _ in self._fields_}
 
 
 class Material(C.Structure):
@@ -122,7 +125,8 @@ def device_lib():
         L.rtmi_version.restype = C.c_char_p
         for name in ("rtmi_create", "rtmi_destroy", "rtmi_set_stream", "rtmi_upload_scene", "rtmi_set_camera", "rtmi_set_seeds", "rtmi_reset_accumulator",
                      "rtmi_set_accumulator", "rtmi_render", "rtmi_trace_primary", "rtmi_trace_rays", "rtmi_finalize", "rtmi_postprocess",
-                     "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_flush", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats"):
+                     "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_flush", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats",
+                     "rtmi_use_own_stream", "rtmi_set_option", "rtmi_get_option", "rtmi_reduce_accumulator"):
             getattr(L, name).restype = C.c_int
         L.rtmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.rtmi_destroy.argtypes = [C.c_void_p]
@@ -144,6 +148,10 @@ def device_lib():
         L.rtmi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rtmi_reset_stats.argtypes = [C.c_void_p]
         L.rtmi_last_error.argtypes = [C.c_void_p]
+        L.rtmi_use_own_stream.argtypes = [C.c_void_p]
+        L.rtmi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+        L.rtmi_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
+        L.rtmi_reduce_accumulator.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _dev = L
     return _dev
 
@@ -163,6 +171,9 @@ def host_lib():
         L.rth_scene_add_sphere.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
         L.rth_scene_add_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(Material), C.c_float, C.c_float, C.c_float]
         L.rth_scene_add_torus_knot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
+        L.rth_scene_add_plane.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
+        L.rth_scene_add_quad.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.POINTER(Material)]
+        L.rth_scene_add_cube.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Material)]
         L.rth_scene_load_obj.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Material), C.c_float, C.c_float, C.c_float]
         L.rth_scene_load_texture_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
         L.rth_scene_finalize.argtypes = [C.c_void_p, C.c_int]
@@ -189,6 +200,10 @@ def host_lib():
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
         L.rth_renderer_set_postfx.argtypes = [C.c_void_p, C.POINTER(PostFx), C.c_int]
         L.rth_renderer_key.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rth_camera_script.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rth_renderer_set_fov.argtypes = [C.c_void_p, C.c_int]
+        L.rth_renderer_set_aspect.argtypes = [C.c_void_p, C.c_float]
+        L.rth_renderer_camera.argtypes = [C.c_void_p, C.c_void_p]
         L.rth_renderer_frames.argtypes = [C.c_void_p]
         L.rth_renderer_frames.restype = C.c_uint
         L.rth_renderer_pixels.argtypes = [C.c_void_p]
@@ -234,6 +249,17 @@ class HostScene:
 
     def add_sphere(self, pos, r, mat):
         self.L.rth_scene_add_sphere(self.h, pos[0], pos[1], pos[2], r, C.byref(mat))
+
+    def add_plane(self, normal, d, mat):
+        self.L.rth_scene_add_plane(self.h, normal[0], normal[1], normal[2], d, C.byref(mat))
+
+    def add_quad(self, size, T16, mat):
+        T16 = np.ascontiguousarray(T16, np.float32).reshape(16)
+        self.L.rth_scene_add_quad(self.h, size, _ptr(T16), C.byref(mat))
+
+    def add_cube(self, pos, size, M16, mat):
+        pos, size, M16 = (np.ascontiguousarray(x, np.float32) for x in (pos, size, M16))
+        self.L.rth_scene_add_cube(self.h, _ptr(pos), _ptr(size), _ptr(M16.reshape(16)), C.byref(mat))
 
     def add_triangles(self, v9, mat, offset=(0, 0, 0)):
         v9 = np.ascontiguousarray(v9, np.float32).reshape(-1, 9)
@@ -311,7 +337,7 @@ def default_camera(w, h, scale=1.0):
 class Device:
     """One rtmi_ctx (one GPU)."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, **options):
         self.L = device_lib()
         self.W, self.H = width, height
         h = C.c_void_p()
@@ -320,6 +346,8 @@ class Device:
             raise RtmiError("rtmi_create failed with status %d (no GPU visible?)" % r)
         self.h = h
         self._keep = None
+        for k, v in options.items():  # rtmi_set_option per handle, e.g. Device(w, h, wide=0, carry_cap=1000)
+            self.set_option(k, v)
 
     def close(self):
         if self.h:
@@ -349,7 +377,23 @@ class Device:
         self._chk(self.L.rtmi_set_seeds(self.h, _ptr(seeds)))
 
     def set_stream(self, stream_ptr):
+        """run on this HIP stream (a torch stream's .cuda_stream); 0 is HIP's null stream, not "none" (see use_own_stream)"""
         self._chk(self.L.rtmi_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def use_own_stream(self):
+        self._chk(self.L.rtmi_use_own_stream(self.h))
+
+    def set_option(self, key, value):
+        self._chk(self.L.rtmi_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_longlong()
+        self._chk(self.L.rtmi_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def reduce_accumulator(self, rccl_comm, root=0):
+        """one ncclReduce (root >= 0) / ncclAllReduce (root < 0) of the float4 accumulators on the handle's stream"""
+        self._chk(self.L.rtmi_reduce_accumulator(self.h, C.c_void_p(rccl_comm), int(root)))
 
     def set_accumulator(self, dev_ptr):
         self._chk(self.L.rtmi_set_accumulator(self.h, C.c_void_p(dev_ptr)))
@@ -453,6 +497,21 @@ class Renderer:
 
     def set_postfx(self, fx, on=True):
         self.L.rth_renderer_set_postfx(self.h, C.byref(fx), int(on))
+
+    def key(self, key, down):
+        """Renderer::KeyDown / KeyUp with a GLFW key code (renderer.cpp:368-441)"""
+        self.L.rth_renderer_key(self.h, int(key), int(bool(down)))
+
+    def set_fov(self, fov):
+        self.L.rth_renderer_set_fov(self.h, int(fov))
+
+    def set_aspect(self, aspect):
+        self.L.rth_renderer_set_aspect(self.h, float(aspect))
+
+    def camera(self):
+        cam = np.zeros(16, np.float32)
+        self.L.rth_renderer_camera(self.h, _ptr(cam))
+        return cam
 
     @property
     def frames(self):

@@ -396,6 +396,135 @@ __device__ __forceinline__ bool traverse_wide( const DScene& s, f3 O, f3 D, f3 r
 	return false;
 }
 
+// ---- the same walk by a TEAM of four lanes (k_tail_team) ----------------------------------------------------------------
+// A path that is alone in its wave (the last few thousand paths of a render) pays for every instruction of its walk at the
+// issue rate of one wave, about 4 cycles each.  Four neighbouring lanes (a DPP quad) therefore share one ray: every
+// lane holds the same ray and the same traversal state, lane j of the team tests child j of a 4-wide node, the four keys
+// are ranked with three quad rotations (1 VALU op each, no LDS), and the team's stack lives in one LDS column.  Nodes are
+// visited in exactly the order wide_step visits them and leaf primitives are judged in leaf order, so a team returns what a
+// single lane returns, bit for bit.
+#define RT_QUAD_ROT1( x ) __builtin_amdgcn_update_dpp( 0, (int)( x ), 0x39, 0xF, 0xF, false ) /* lane j reads lane j+1 of its quad */
+#define RT_QUAD_ROT2( x ) __builtin_amdgcn_update_dpp( 0, (int)( x ), 0x4E, 0xF, 0xF, false )
+#define RT_QUAD_ROT3( x ) __builtin_amdgcn_update_dpp( 0, (int)( x ), 0x93, 0xF, 0xF, false )
+#define RT_QUAD_BCAST( x, l ) __builtin_amdgcn_update_dpp( 0, (int)( x ), ( l ) * 0x55, 0xF, 0xF, false ) /* every lane reads lane l of its quad */
+#define RT_MISS_KEY 0xFFFFFFFFu
+template <bool ANY>
+__device__ __forceinline__ uint32_t team_wide_step( const DScene& s, uint32_t cur, int j, f3 O, f3 rD, float t, volatile uint32_t* stack, const int stride, int& sp )
+{
+	const float4 q0 = s.wide[4 * cur], q2 = s.wide[4 * cur + 2], q3 = s.wide[4 * cur + 3];
+	const uint32_t ref = ( (const uint32_t*)s.wide )[16 * cur + 4 + j];
+	const uint32_t ex = __float_as_uint( q0.w );
+	const float sx = __uint_as_float( ( ex & 255u ) << 23 ), sy = __uint_as_float( ( ( ex >> 8 ) & 255u ) << 23 ), sz = __uint_as_float( ( ( ex >> 16 ) & 255u ) << 23 );
+	const uint32_t sh = 8u * (uint32_t)j;
+	const uint32_t lox = ( __float_as_uint( q2.x ) >> sh ) & 255u, loy = ( __float_as_uint( q2.y ) >> sh ) & 255u, loz = ( __float_as_uint( q2.z ) >> sh ) & 255u;
+	const uint32_t hix = ( __float_as_uint( q2.w ) >> sh ) & 255u, hiy = ( __float_as_uint( q3.x ) >> sh ) & 255u, hiz = ( __float_as_uint( q3.y ) >> sh ) & 255u;
+	// the same operations as wide_step, child j only: plane = fma(byte, 2^e, origin), then (plane - O) * rD
+	const float tnx = ( __builtin_fmaf( (float)( rD.x < 0 ? hix : lox ), sx, q0.x ) - O.x ) * rD.x, tfx = ( __builtin_fmaf( (float)( rD.x < 0 ? lox : hix ), sx, q0.x ) - O.x ) * rD.x;
+	const float tny = ( __builtin_fmaf( (float)( rD.y < 0 ? hiy : loy ), sy, q0.y ) - O.y ) * rD.y, tfy = ( __builtin_fmaf( (float)( rD.y < 0 ? loy : hiy ), sy, q0.y ) - O.y ) * rD.y;
+	const float tnz = ( __builtin_fmaf( (float)( rD.z < 0 ? hiz : loz ), sz, q0.z ) - O.z ) * rD.z, tfz = ( __builtin_fmaf( (float)( rD.z < 0 ? loz : hiz ), sz, q0.z ) - O.z ) * rD.z;
+	const float tmin = fmaxf( fmaxf( fmaxf( tnx, tny ), tnz ), 0.0f ), tmax = fminf( fminf( fminf( tfx, tfy ), tfz ), t );
+	const uint32_t key = tmin <= tmax ? ( ( __float_as_uint( tmin ) & ~3u ) | (uint32_t)j ) : RT_MISS_KEY;
+	const uint32_t k1 = (uint32_t)RT_QUAD_ROT1( key ), k2 = (uint32_t)RT_QUAD_ROT2( key ), k3 = (uint32_t)RT_QUAD_ROT3( key );
+	const bool hit = key != RT_MISS_KEY;
+	const int rank = (int)( k1 < key ) + (int)( k2 < key ) + (int)( k3 < key ); // valid keys differ in their two lowest bits
+	const int nhit = (int)hit + (int)( k1 != RT_MISS_KEY ) + (int)( k2 != RT_MISS_KEY ) + (int)( k3 != RT_MISS_KEY );
+	if (nhit == 0) return sp > 0 ? stack[--sp * stride] : RT_DONE; // (the same for the four lanes)
+	// the nearest child next, the others on the stack, farthest deepest (as wide_step pushes them)
+	if (hit && rank >= 1) stack[( sp + nhit - 1 - rank ) * stride] = ref;
+	sp += nhit - 1;
+	uint32_t next = hit && rank == 0 ? ref : 0u;
+	next |= (uint32_t)RT_QUAD_ROT1( next ), next |= (uint32_t)RT_QUAD_ROT2( next ); // after ROT1 lane j holds j | j+1, after ROT2 all four
+	return next;
+}
+// One leaf primitive without the comparison against the incumbent hit: the distances isect_prim would consider, in its
+// order (a sphere has two), and whether each passes its own test (Triangle::Intersect primitive.h:50-72 up to `t > 0.0001f`,
+// Sphere::Intersect :108-127 up to `t > 0`).
+struct PrimCand { float t1, t2; int obj; bool v1, v2; };
+__device__ __forceinline__ void prim_candidates( const DScene& s, int pos, f3 O, f3 D, PrimCand& c )
+{
+	c.v1 = false, c.v2 = false, c.t1 = 0, c.t2 = 0;
+	const float4 a = s.prims[3 * pos], b = s.prims[3 * pos + 1];
+	c.obj = __float_as_int( b.w );
+	if (__float_as_int( a.w ) == 0)
+	{
+		const float4 cc = s.prims[3 * pos + 2];
+		const f3 p1 = mk3( a ), edge1 = mk3( b ), edge2 = mk3( cc );
+		const f3 hh = cross3( D, edge2 );
+		const float det = dot3( edge1, hh );
+		if (det > -0.0001f && det < 0.0001f) return;
+		const float f = 1 / det;
+		const f3 sv = O - p1;
+		const float u = f * dot3( sv, hh );
+		if (u < 0 || u > 1) return;
+		const f3 q = cross3( sv, edge1 );
+		const float v = f * dot3( D, q );
+		if (v < 0 || u + v > 1) return;
+		c.t1 = f * dot3( edge2, q );
+		c.v1 = c.t1 > 0.0001f;
+		return;
+	}
+	const f3 oc = O - mk3( a );
+	const float bb = dot3( oc, D );
+	const float cc = dot3( oc, oc ) - b.x;
+	float d = bb * bb - cc;
+	if (d <= 0) return;
+	d = sqrtf( d );
+	c.t1 = -bb - d, c.v1 = c.t1 > 0;
+	c.t2 = d - bb, c.v2 = c.t2 > 0;
+}
+// The walk over the 4-wide nodes by a team (see traverse_wide for the single-lane form it reproduces).  Every lane of the
+// team passes the same ray, hit and stack column; `j` is the lane's number in its team.  Returns true iff ANY and occluded.
+template <bool ANY>
+__device__ __forceinline__ bool team_traverse_wide( const DScene& s, int j, f3 O, f3 D, f3 rD, RayHit& h, volatile uint32_t* stack, const int stride, uint32_t& nSteps, uint32_t& nPrims )
+{
+	uint32_t cur = s.wide_root;
+	int sp = 0;
+	while (true)
+	{
+		while (!( cur & RT_LEAF )) { cur = team_wide_step<ANY>( s, cur, j, O, rD, h.t, stack, stride, sp ); nSteps++; }
+		if (cur == RT_DONE) break;
+		const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
+		// the exact box of the leaf: a hit found under quantised boxes counts only if this passes the reference's test (traverse_wide)
+		const float4 b0 = s.leafbox[2 * first], b1 = s.leafbox[2 * first + 1];
+		float tmn, tmx;
+		slab<false>( b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, O, rD, tmn, tmx );
+		const bool boxAlive = tmx >= tmn && tmx > 0;
+		for (int base = 0; base < count; base += 4)
+		{
+			PrimCand c;
+			c.v1 = false, c.v2 = false, c.t1 = 0, c.t2 = 0, c.obj = -1;
+			if (base + j < count) prim_candidates( s, first + base + j, O, D, c ); // lane j: primitive base + j of the leaf
+			nPrims += (uint32_t)( count - base < 4 ? count - base : 4 );
+			if (ANY)
+			{
+				// IntersectBVHShadowRay: any primitive closer than the ray's (fixed) t occludes
+				bool occ = boxAlive && tmn < h.t && ( ( c.v1 && c.t1 < h.t ) || ( c.v2 && c.t2 < h.t ) );
+				occ = occ | ( RT_QUAD_ROT1( occ ) != 0 ), occ = occ | ( RT_QUAD_ROT2( occ ) != 0 );
+				if (occ) return true;
+			}
+			else
+			{
+				// judge the up to four results in leaf order, each against the hit as the earlier ones left it: what isect_prim
+				// does primitive by primitive (strict <, or equal distance and earlier leaf position)
+#define RT_JUDGE( l )                                                                                                                              \
+				if (base + ( l ) < count) /* (the same for the four lanes) */                                                                          \
+				{                                                                                                                                      \
+					const bool v1 = RT_QUAD_BCAST( c.v1, l ) != 0, v2 = RT_QUAD_BCAST( c.v2, l ) != 0;                                                 \
+					const float t1 = __int_as_float( RT_QUAD_BCAST( __float_as_int( c.t1 ), l ) ), t2 = __int_as_float( RT_QUAD_BCAST( __float_as_int( c.t2 ), l ) ); \
+					const int obj = RT_QUAD_BCAST( c.obj, l ), pos = first + base + ( l );                                                              \
+					const bool a1 = v1 && ( t1 < h.t || ( t1 == h.t && pos < h.pos ) );                                                                \
+					const bool a2 = !a1 && v2 && ( t2 < h.t || ( t2 == h.t && pos < h.pos ) );                                                         \
+					if (( a1 || a2 ) && boxAlive && tmn <= h.t) h.t = a1 ? t1 : t2, h.obj = obj, h.pos = pos;                                           \
+				}
+				RT_JUDGE( 0 ) RT_JUDGE( 1 ) RT_JUDGE( 2 ) RT_JUDGE( 3 )
+#undef RT_JUDGE
+			}
+		}
+		cur = sp > 0 ? stack[--sp * stride] : RT_DONE;
+	}
+	return false;
+}
+
 // Scene::FindNearest (scene.h:359-368): quads[0], cubes[0], planes, BVH.  h.t carries the ray's tmax in.
 template <bool COUNT>
 __device__ __forceinline__ void find_nearest( const DScene& s, f3 O, f3 D, RayHit& h, uint32_t* stack, int stride, TravCount& cnt )

@@ -33,6 +33,10 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <dlfcn.h>
+#include <chrono>
 
 #define BLOCK 256   // traversal and per-pixel kernels
 #define SBLOCK 1024 // shading / ray-generation kernels: one queue-append atomic per 1024 paths (see block_append)
@@ -68,6 +72,7 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 	uint32_t pad[2];
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
 	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
+	unsigned long long tail_prof[8]; // option tail_profile: see rtmi_stats.tail_profile
 };
 
 #define FLAG_SPECULAR 1u
@@ -128,9 +133,9 @@ __device__ __forceinline__ void primary_ray( const CamProp& cam, float x, float 
 // The part of Scene::FindNearest that needs no BVH walk, done by the kernel that CREATES the ray while it still has it
 // in registers (every lane busy): quads[0], cubes[0], planes (scene.h:361-362, bvh.h:498-502), the reciprocal
 // direction and the root box test.  Returns true when the ray has to walk the BVH.
-__device__ __forceinline__ bool begin_closest( const DScene& s, f3 O, f3 D, RayHit& h )
+__device__ __forceinline__ bool begin_closest( const DScene& s, f3 O, f3 D, RayHit& h, float t0 = 1e34f )
 {
-	h.t = 1e34f, h.obj = -1, h.pos = -1;
+	h.t = t0, h.obj = -1, h.pos = -1;
 	isect_analytic( s, O, D, h );
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
@@ -194,9 +199,16 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 // parked rays, a bounce late), so they are not added into the float chain E[slot] but summed EXACTLY: 64-bit fixed point,
 // 2^-40 units, integer atomics.  Integer addition is associative, so the sum does not depend on arrival order and no
 // read-modify-write of a float is shared between lanes; k_accumulate adds float(Es) to the path's E once.
-// (Range +-2^23; a contribution below 2^-40 ~ 1e-12 is dropped.  A non-finite one goes to E so that it stays visible.)
+// (A contribution below 2^-40 ~ 1e-12 is dropped.)
 #define ES_SCALE 1099511627776.0f // 2^40
-__device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* E, uint32_t slot, float4 c )
+// (Range +-2^22.  A contribution that is not finite or larger goes to odd[pixel], a float4 per pixel that is touched by
+// float atomics ONLY -- no plain read-modify-write of another kernel can lose it -- and is added to the accumulator by
+// k_fold_late at the next read, when nothing else is in flight: it stays visible, as NaN / inf / a huge value.)
+__device__ __forceinline__ void add_odd( float4* odd, uint32_t pixel, float x, float y, float z )
+{
+	atomicAdd( &odd[pixel].x, x ), atomicAdd( &odd[pixel].y, y ), atomicAdd( &odd[pixel].z, z );
+}
+__device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* odd, uint32_t WH, uint32_t slot, float4 c )
 {
 	const bool finite = fabsf( c.x ) < 4194304.0f && fabsf( c.y ) < 4194304.0f && fabsf( c.z ) < 4194304.0f; // false for NaN
 	if (finite)
@@ -207,7 +219,7 @@ __device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* 
 		if (y) atomicAdd( p + 1, (unsigned long long)y );
 		if (z) atomicAdd( p + 2, (unsigned long long)z );
 	}
-	else atomicAdd( &E[slot].x, c.x ), atomicAdd( &E[slot].y, c.y ), atomicAdd( &E[slot].z, c.z );
+	else add_odd( odd, slot % WH, c.x, c.y, c.z );
 }
 
 // Where a path's radiance goes.  Up to its 15th vertex a path adds into its own slot: E[slot] is the float chain of
@@ -217,7 +229,7 @@ __device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* 
 // 64-bit fixed-point sum per pixel that is folded into the accumulator when the caller next reads it.  A late path owes
 // its batch nothing any more, so the batch's slot can be accumulated and reused while the path is still bouncing -- in
 // the queues of the following batches (k_carry_out / k_carry_in), at wavefront efficiency, instead of in a tail of its own.
-struct Sinks { float4* E; long long* Es; long long* late; float4* acc; uint32_t WH; };
+struct Sinks { float4* E; long long* Es; long long* late; float4* odd; uint32_t WH; };
 __device__ __forceinline__ void add_late( const Sinks& k, uint32_t slot, f3 c )
 {
 	const uint32_t p = slot % k.WH;
@@ -230,7 +242,7 @@ __device__ __forceinline__ void add_late( const Sinks& k, uint32_t slot, f3 c )
 		if (y) atomicAdd( q + 1, (unsigned long long)y );
 		if (z) atomicAdd( q + 2, (unsigned long long)z );
 	}
-	else atomicAdd( &k.acc[p].x, c.x ), atomicAdd( &k.acc[p].y, c.y ), atomicAdd( &k.acc[p].z, c.z ); // stays visible
+	else add_odd( k.odd, p, c.x, c.y, c.z );
 }
 // a contribution of the float chain (light hit, unoccluded shadow ray without a walk)
 __device__ __forceinline__ void add_chain( const Sinks& k, uint32_t slot, bool late, f3 c )
@@ -244,7 +256,7 @@ __device__ __forceinline__ void add_chain( const Sinks& k, uint32_t slot, bool l
 __device__ __forceinline__ void add_walked( const Sinks& k, uint32_t slot, bool late, float4 c )
 {
 	if (late) add_late( k, slot, mk3( c ) );
-	else add_shadow_contribution( k.Es, k.E, slot, c );
+	else add_shadow_contribution( k.Es, k.odd, k.WH, slot, c );
 }
 
 // Tail control: a launch lasts as long as its longest ray, and a few rays of this scene walk > 1500 steps against a
@@ -489,7 +501,8 @@ struct Vertex
 	f3 newO, newD, shO, shD, contrib;
 	float shT;
 };
-__device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float t, int obj, f3& T, uint32_t& rng, uint32_t& flags, const Sinks& sinks, uint32_t slot, bool late, Vertex& v )
+// `emit`: this lane adds the light hit to the sinks (false for the three lanes of a k_tail_team team that only mirror the leader's arithmetic)
+__device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float t, int obj, f3& T, uint32_t& rng, uint32_t& flags, const Sinks& sinks, uint32_t slot, bool late, Vertex& v, bool emit = true )
 {
 	v.push_next = false, v.shadow_any = false, v.shT = 0;
 	if (obj == -1) return; // miss: the path ends, Sample returns E (renderer.cpp:254, 363)
@@ -502,7 +515,7 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 	{
 		if (flags & FLAG_SPECULAR) // renderer.cpp:262-263: E + T * emission
 		{
-			add_chain( sinks, slot, late, T * mk3( s.light_emission ) );
+			if (emit) add_chain( sinks, slot, late, T * mk3( s.light_emission ) );
 		}
 		return;
 	}
@@ -680,8 +693,9 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // round holds one long path, and a thousand almost-empty resident waves would starve the next batches' bulk kernels).
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
+template <bool PROF>
 __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t team_below, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
@@ -696,6 +710,9 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	// the chip is this kernel's, so a round (round 0 excepted) spreads its paths over all the waves of the grid, as few to a
 	// wave as that allows: a path's bounce waits for the walks of the others in its wave
 	const bool hurry = dense_above != 0 && *(const volatile uint32_t*)draining != 0;
+	if (hurry && n <= team_below) return; // this round is k_tail_team's (launched right after this kernel with the same arguments)
+	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0;
 	int per_wave;
 	if (hurry)
 	{
@@ -736,7 +753,9 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 			{
 				// Scene::FindNearest from scratch (the analytic part stored with the entry is recomputed: same bits)
 				RayHit h;
+				unsigned long long tp = PROF ? wall_clock64() : 0;
 				const bool walk = begin_closest( s, O, D, h );
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[0] += x - tp, tp = x, prof[4]++; }
 				nExt++;
 				if (walk)
 				{
@@ -747,10 +766,12 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 					else if (s.wide) traverse_wide<false>( s, O, D, rD, h, stack, per_wave );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
 				}
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x; }
 				Vertex v;
 				const bool late = age == META_AGE_LATE;
 				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v );
 				age = age < META_AGE_LATE ? age + 1 : age;
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[2] += x - tp, tp = x; }
 				if (v.shadow_any)
 				{
 					nSh++;
@@ -768,6 +789,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 						if (!occ) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
 				}
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
 				if (!v.push_next) { alive = false; break; }
 				O = v.newO, D = v.newD;
 			}
@@ -791,6 +813,133 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	} // next per_wave paths
 	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
+	if (PROF)
+	{
+		for (int k = 0; k < 5; k++) wave_add64( prof[k], &ctr->tail_prof[k] );
+		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 );
+	}
+}
+
+// ---- the end of a render: teams of four lanes per path -------------------------------------------------------------------
+// When the caller waits for the image the chip is empty except for the last paths, a few thousand at most, a handful of
+// which bounce thousands of times inside the closed mirror object (the reference has no bounce limit, renderer.cpp:251): the
+// wait is (bounces of the longest path) x (latency of one bounce).  One path alone in a wave pays about 4 cycles for every
+// instruction of its walk, so here four neighbouring lanes walk ONE path together (rt_device.h: team_traverse_wide): lane j
+// tests child j of every 4-wide node and primitive j of every leaf, the rest of the bounce (analytic tests, shading, the
+// random stream) is computed identically by the four lanes, and lane 0 alone writes.  Same visiting order, same
+// arithmetic, same results as k_tail, which stays in charge of every round that is not a draining round with few paths.
+template <bool PROF>
+__global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
+	uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t team_below, DevCounters* ctr )
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t n = *n_in;
+	if (!( *(const volatile uint32_t*)draining != 0 && n <= team_below )) return; // k_tail's round
+	// teams per wave: as few as the grid allows (a team's bounce waits for the divergence of the other teams of its wave)
+	const uint32_t waves_per_block = blockDim.x >> 6, waves = gridDim.x * waves_per_block;
+	const uint32_t need = ( n + waves - 1 ) / waves;
+	uint32_t per_wave = 1;
+	while (per_wave < need && per_wave < 16) per_wave *= 2;
+	const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+	if (( blockIdx.x * waves_per_block + wave_in_block ) * per_wave >= n) return; // wave-uniform: surplus waves leave at once
+	const int j = (int)( lane & 3u );
+	const uint32_t tm = lane >> 2;
+	const int stride = (int)( waves_per_block * 16u );
+	volatile uint32_t* stack = lds_stack + wave_in_block * 16u + tm; // one column per team
+	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
+	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0;
+	uint32_t nSteps = 0, nPrims = 0;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	for (;;)
+	{
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd( &ctr->pool_tail, per_wave );
+		base = __shfl( base, 0, 64 );
+		if (base >= n) break; // wave-uniform
+		const uint32_t i = base + tm;
+		bool alive = false;
+		uint32_t slot = 0, flags = 0, rng = 0, age = 0;
+		f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), T = mk3( 0, 0, 0 );
+		if (i < n && tm < per_wave) // the same for the four lanes of a team
+		{
+			const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
+			const uint32_t meta = in.meta[i];
+			slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w ), age = ( meta >> META_AGE_SHIFT ) & META_AGE_LATE;
+			O = mk3( ot ), D = mk3( dh ), T = mk3( ts );
+			alive = true;
+			for (int nb = 0; nb < max_bounces; nb++)
+			{
+				RayHit h;
+				unsigned long long tp = PROF ? wall_clock64() : 0;
+				const bool walk = begin_closest( s, O, D, h );
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[0] += x - tp, tp = x, prof[4]++; }
+				if (j == 0) nExt++;
+				if (walk)
+				{
+					if (j == 0) nExtWalk++;
+					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+					// rays that the 4-wide nodes cannot take walk the pairs, the four lanes in step (same values to the same column)
+					if (inexact) traverse<false, true, false>( s, O, D, rD, h, const_cast<uint32_t*>( stack ), stride, tc );
+					else if (s.wide) team_traverse_wide<false>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims );
+					else traverse<false, false, false>( s, O, D, rD, h, const_cast<uint32_t*>( stack ), stride, tc );
+				}
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x; }
+				Vertex v;
+				const bool late = age == META_AGE_LATE;
+				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v, j == 0 );
+				age = age < META_AGE_LATE ? age + 1 : age;
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[2] += x - tp, tp = x; }
+				if (v.shadow_any)
+				{
+					if (j == 0) nSh++;
+					bool occluded, swalk;
+					begin_any( s, v.shO, v.shD, v.shT, occluded, swalk );
+					if (!occluded && !swalk) { if (j == 0) add_chain( sinks, slot, late, v.contrib ); }
+					else if (swalk)
+					{
+						if (j == 0) nShWalk++;
+						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
+						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
+						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, const_cast<uint32_t*>( stack ), stride, tc )
+							: s.wide ? team_traverse_wide<true>( s, j, v.shO, v.shD, rD, sh, stack, stride, nSteps, nPrims )
+							: traverse<true, false, false>( s, v.shO, v.shD, rD, sh, const_cast<uint32_t*>( stack ), stride, tc );
+						if (!occ && j == 0) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
+					}
+				}
+				if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
+				if (!v.push_next) { alive = false; break; }
+				O = v.newO, D = v.newD;
+			}
+		}
+		// survivors of this round, compacted (one atomic per wave); a team's leader writes
+		const bool keep = alive && j == 0;
+		const unsigned long long m = __ballot( keep );
+		if (m)
+		{
+			const int leader = __ffsll( (long long)m ) - 1;
+			uint32_t b0 = 0;
+			if ((int)lane == leader) b0 = atomicAdd( n_out, (uint32_t)__popcll( m ) );
+			const uint32_t k = __shfl( b0, leader, 64 ) + __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) );
+			if (keep)
+			{
+				out.o_t[k] = make_float4( O.x, O.y, O.z, 1e34f );
+				out.d_h[k] = make_float4( D.x, D.y, D.z, __int_as_float( -1 ) );
+				out.T_s[k] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+				out.meta[k] = slot | ( age << META_AGE_SHIFT ) | ( flags << 30 );
+			}
+		}
+	} // next per_wave paths
+	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
+	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
+	if (PROF)
+	{
+		prof[5] = nSteps, prof[6] = nPrims;
+		for (int k = 0; k < 7; k++) wave_add64( j == 0 ? prof[k] : 0ull, &ctr->tail_prof[k] );
+		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 );
+	}
 }
 
 // ---- carry: the late paths (Sinks) that are alive when a batch leaves the wavefront loop join the NEXT batch's queue ------
@@ -852,16 +1001,19 @@ __global__ void k_carry_commit( uint32_t* n_st, uint32_t* n_carry, uint32_t cap 
 	*n_carry = 0;
 }
 // accumulator[p] += the exact sum of the late contributions of pixel p, which starts again at zero
-__global__ __launch_bounds__( BLOCK ) void k_fold_late( float4* __restrict__ acc, long long* __restrict__ late, int WH )
+__global__ __launch_bounds__( BLOCK ) void k_fold_late( float4* __restrict__ acc, long long* __restrict__ late, float4* __restrict__ odd, int WH )
 {
 	const int p = blockIdx.x * BLOCK + threadIdx.x;
 	if (p >= WH) return;
 	const longlong2 s01 = *(const longlong2*)( late + 4 * (size_t)p );
 	const long long s2 = late[4 * (size_t)p + 2];
-	if (( s01.x | s01.y | s2 ) == 0) return;
+	const float4 o = odd[p]; // contributions that did not fit the fixed-point sums (add_odd); almost always +0
+	const bool anyOdd = ( __float_as_uint( o.x ) | __float_as_uint( o.y ) | __float_as_uint( o.z ) ) != 0;
+	if (( s01.x | s01.y | s2 ) == 0 && !anyOdd) return;
 	const float inv = 1.0f / ES_SCALE;
 	float4 a = acc[p];
 	a.x += (float)s01.x * inv, a.y += (float)s01.y * inv, a.z += (float)s2 * inv;
+	if (anyOdd) a.x += o.x, a.y += o.y, a.z += o.z, odd[p] = make_float4( 0, 0, 0, 0 );
 	acc[p] = a;
 	late[4 * (size_t)p] = 0, late[4 * (size_t)p + 1] = 0, late[4 * (size_t)p + 2] = 0;
 }
@@ -1013,6 +1165,55 @@ __global__ __launch_bounds__( BLOCK ) void k_copy_hits( PathState st, int n, int
 	const int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
 	obj_out[i] = __float_as_int( st.d_h[i].w ), t_out[i] = st.o_t[i].w;
+}
+// The same hook through the render path's own machinery (option hook_kernel = 1): caller rays become entries of a path queue
+// (closest hit) or of a shadow queue (any hit) exactly as k_primary / k_shade would have queued them, and k_trace walks them.
+// An unoccluded shadow ray adds its "contribution" (1, 0, 0) to Es[ray]; k_rays_any_result turns that back into a flag.
+__global__ __launch_bounds__( SBLOCK ) void k_rays_begin( DScene s, int n, const float* __restrict__ O3, const float* __restrict__ D3, const float* __restrict__ tmax, int any_hit,
+	PathState st, ShadowQueue sq, float4* __restrict__ Es, uint32_t* __restrict__ wq, int* __restrict__ obj_out, float* __restrict__ t_out, DevCounters* ctr )
+{
+	__shared__ uint32_t lds[2 * 16];
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool walk = false, swalk = false;
+	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 );
+	float tm = 0;
+	if (i < n)
+	{
+		O = mk3( O3[3 * i], O3[3 * i + 1], O3[3 * i + 2] ), D = mk3( D3[3 * i], D3[3 * i + 1], D3[3 * i + 2] ), tm = tmax[i];
+		if (any_hit)
+		{
+			bool occluded;
+			begin_any( s, O, D, tm, occluded, swalk );
+			obj_out[i] = occluded ? 1 : ( swalk ? 2 : 0 ), t_out[i] = tm;
+			Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 );
+		}
+		else
+		{
+			RayHit h;
+			walk = begin_closest( s, O, D, h, tm );
+			st.o_t[i] = make_float4( O.x, O.y, O.z, h.t );
+			st.d_h[i] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+			st.T_s[i] = make_float4( 0, 0, 0, 0 );
+			st.meta[i] = (uint32_t)i;
+		}
+	}
+	const bool push[2] = { walk, swalk };
+	uint32_t* const counters[2] = { &ctr->n_walk[0], &ctr->n_shadow[0] };
+	uint32_t idx[2];
+	block_append<2>( push, counters, idx, lds );
+	if (walk) wq[idx[0]] = (uint32_t)i;
+	if (swalk)
+	{
+		sq.o_t[idx[1]] = make_float4( O.x, O.y, O.z, tm );
+		sq.d_s[idx[1]] = make_float4( D.x, D.y, D.z, __uint_as_float( (uint32_t)i ) );
+		sq.c[idx[1]] = make_float4( 1, 0, 0, 0 );
+	}
+	if (i == 0) ctr->n_state[0] = (uint32_t)n;
+}
+__global__ __launch_bounds__( BLOCK ) void k_rays_any_result( const long long* __restrict__ Es, int n, int* __restrict__ obj_out )
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n && obj_out[i] == 2) obj_out[i] = Es[4 * (size_t)i] != 0 ? 0 : 1;
 }
 
 // ---- Whitted / debug views: Renderer::Trace without recursion (renderer.cpp:80-244) ------------------------
@@ -1217,6 +1418,7 @@ struct rtmi_ctx
 	uint32_t* draining = 0, *draining_dev = 0; // pinned, device-mapped flag read by k_tail (see there)
 	// late paths (Sinks): exact per-pixel sums, and the buffer in which the late survivors of a batch wait for the next one
 	long long* late = 0;         // 4 x int64 per pixel
+	float4* odd = 0;             // per pixel: contributions outside the fixed-point range (add_odd), folded with `late`
 	PathState carry[2] = {};     // [0] collects (k_carry_out) and feeds (k_carry_in); [1] is the ping-pong partner of the final tail
 	DevCounters* carry_ctr = 0;  // n_state[0] = paths in carry[0]
 	uint32_t carry_cap = 1u << 23, left_cap = 1u << 16;
@@ -1232,8 +1434,22 @@ struct rtmi_ctx
 	int tail_waves = 16;         // resident k_tail waves per CU
 	int tail_block = 4;          // waves per k_tail workgroup (RTMI_TAIL_BLOCK)
 	uint32_t tail_dense = 4096, tail_mid = 0; // k_tail: 64 paths per wave above tail_dense live paths, 16 above tail_mid, else tail_lanes
-	bool log_bounces = false;   // RTMI_LOG_BOUNCES: print the path count per bounce (diagnostics)
+	bool log_bounces = false;   // option log_bounces: print the path count per bounce (diagnostics)
 	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
+	int batch_opt = 0;          // option batch: samples per render batch (0 = as many as 2^25 paths allow)
+	int blocks_per_cu_opt = 0;  // option blocks_per_cu: resident walk blocks per CU (0 = min(4, what the LDS stack allows))
+	bool tail_paths_set = false;
+	bool check_launches = false; // option check_launches: synchronise and check after every bounce (localises a fault; slow)
+	int hook_kernel = 0;        // option hook_kernel: rtmi_trace_rays runs 0 = k_trace_rays (one ray per lane over the reference's pairs),
+	                            // 1 = the render path's own queues and persistent walk (k_trace: 4-wide nodes where built)
+	bool tail_team = true;      // option tail_team: the end-of-render rounds run k_tail_team (four lanes per path) once few paths are left
+	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
+	uint32_t team_below = 1u << 14; // option team_below: live paths at or below which a draining round uses k_tail_team
+	// device scratch of the parity hooks and rtmi_postprocess, grown on demand and kept (no allocation per call)
+	void* hook_buf = 0; size_t hook_cap = 0;
+	uint32_t gamma_host[256]; float gamma_cached = 0; // host image of gamma_lut (lives as long as the copy needs it)
+	void* noalloc_scratch = 0;  // this device's address of the file-scope scratch array (rtmi_trace_rays_noalloc)
+	bool drain_open = false; double drain_t0 = 0;
 	WFrame* frames = 0;
 	int frames_depth = 0;
 	// stats / profiling
@@ -1272,17 +1488,25 @@ template <typename T> static int dev_upload( rtmi_ctx* c, T** p, const T* src, s
 	return RTMI_OK;
 }
 
-static hipEvent_t get_event( rtmi_ctx* c )
+static hipEvent_t get_event( rtmi_ctx* c ) // null when the runtime has no event to give: the measurement is skipped, not the work
 {
 	if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-	hipEvent_t e; (void)hipEventCreate( &e ); return e;
+	hipEvent_t e = 0;
+	if (hipEventCreate( &e ) != hipSuccess) { c->err = "hipEventCreate failed: kernel timing incomplete"; return 0; }
+	return e;
 }
 struct ScopedTimer // records a pair of events around a launch when profiling is on
 {
 	rtmi_ctx* c; int cls; hipEvent_t a = 0, b = 0;
 	hipStream_t st;
-	ScopedTimer( rtmi_ctx* c, int cls, hipStream_t on = 0 ) : c( c ), cls( cls ), st( on ? on : c->stream ) { if (c->prof_events) { a = get_event( c ), b = get_event( c ); (void)hipEventRecord( a, st ); } }
-	~ScopedTimer() { if (c->prof_events) { (void)hipEventRecord( b, st ); c->timed.push_back( { a, b, cls } ); } }
+	ScopedTimer( rtmi_ctx* c, int cls, hipStream_t on ) : c( c ), cls( cls ), st( on )
+	{
+		if (!c->prof_events) return;
+		a = get_event( c ), b = get_event( c );
+		if (a && b) (void)hipEventRecord( a, st );
+		else { if (a) c->ev_pool.push_back( a ); if (b) c->ev_pool.push_back( b ); a = b = 0; }
+	}
+	~ScopedTimer() { if (a && b) { (void)hipEventRecord( b, st ); c->timed.push_back( { a, b, cls } ); } }
 };
 static void resolve_timers( rtmi_ctx* c )
 {
@@ -1339,7 +1563,7 @@ static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 }
 // Everything enqueued by earlier rtmi_render calls (tails and accumulates on the slot streams) happens-before what is
 // enqueued on the handle's stream after this call.
-static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E, k.Es = b.Es, k.late = c->late, k.acc = c->accum, k.WH = (uint32_t)( c->W * c->H ); return k; }
+static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E, k.Es = b.Es, k.late = c->late, k.odd = c->odd, k.WH = (uint32_t)( c->W * c->H ); return k; }
 
 // k_tail rounds of 32, 64, 128, ... bounces over the state set st[cur] (length ctr->n_state[cur], at most `upper`), enqueued
 // blind on `ts` (a round over an empty queue returns at once); survivors are compacted between rounds, the last round has no
@@ -1354,8 +1578,24 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
 		const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->walk_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
 		const uint32_t lds_words = (uint32_t)c->walk_depth * 64u * wpb;
-		hipLaunchKernelGGL( k_tail, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-			round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, ctr );
+		// a draining round with few paths left belongs to k_tail_team (the device knows the live count and whether the host waits:
+		// both kernels are launched, the one whose round it is not returns at once)
+		const uint32_t team_below = c->tail_team && c->ds.wide && round > 0 ? c->team_below : 0u;
+		if (c->tail_profile)
+			hipLaunchKernelGGL( k_tail<true>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
+		else
+			hipLaunchKernelGGL( k_tail<false>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
+		if (team_below)
+		{
+			const uint32_t twaves = std::max( 1u, std::min( max_waves, std::min( upper, team_below ) ) ), tblocks = ( twaves + 3 ) / 4;
+			const size_t tlds = (size_t)c->walk_depth * 64u * sizeof( uint32_t ); // 4 waves x 16 teams, one column each
+			if (c->tail_profile)
+				hipLaunchKernelGGL( k_tail_team<true>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, ctr );
+			else
+				hipLaunchKernelGGL( k_tail_team<false>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, ctr );
+		}
 		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 		cur ^= 1;
 	}
@@ -1364,9 +1604,14 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 
 static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride );
 
+static double now_ms() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+// host time from the call that starts finishing the paths in flight to the return of the blocking call that needed them
+static void drain_closed( rtmi_ctx* c ) { if (c->drain_open) c->stats.ms_drain += now_ms() - c->drain_t0, c->stats.n_drains++, c->drain_open = false; }
+
 static int join_batches( rtmi_ctx* c )
 {
 	if (c->draining) *(volatile uint32_t*)c->draining = 1; // the caller is about to wait for the tails
+	if (c->carry_pending && !c->drain_open) c->drain_open = true, c->drain_t0 = now_ms();
 	if (c->carry_pending && c->has_scene && c->slots[c->next_slot].E)
 	{
 		// The late paths that the last batch handed on have no batch to ride with: they get a batch of their own, without
@@ -1380,8 +1625,8 @@ static int join_batches( rtmi_ctx* c )
 		}
 		if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
 		// fold the late sums of all batches since the last read into the accumulator
-		ScopedTimer t( c, 3 );
-		hipLaunchKernelGGL( k_fold_late, dim3( nblocks( (size_t)c->W * c->H ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->late, c->W * c->H );
+		ScopedTimer t( c, 3, c->stream );
+		hipLaunchKernelGGL( k_fold_late, dim3( nblocks( (size_t)c->W * c->H ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->late, c->odd, c->W * c->H );
 		HIPCHK( hipGetLastError() );
 		c->carry_pending = false;
 		return RTMI_OK;
@@ -1397,12 +1642,146 @@ static int sync_all( rtmi_ctx* c )
 	if (c->side) HIPCHK( hipStreamSynchronize( c->side ) );
 	for (int k = 0; k < MAX_SLOTS; k++) if (c->slots[k].tail_stream) { HIPCHK( hipStreamSynchronize( c->slots[k].tail_stream ) ); c->slots[k].busy = false; }
 	c->last_acc = 0;
+	drain_closed( c );
 	return RTMI_OK;
+}
+
+// ---- options: one table for rtmi_set_option / rtmi_get_option and for the RTMI_<KEY> environment defaults ----------------
+static void free_carry( rtmi_ctx* c )
+{
+	for (int k = 0; k < 2; k++)
+	{
+		void* ps[] = { c->carry[k].o_t, c->carry[k].d_h, c->carry[k].T_s, c->carry[k].meta };
+		for (void* q : ps) if (q) (void)hipFree( q );
+		c->carry[k] = PathState{};
+	}
+}
+static int alloc_carry( rtmi_ctx* c )
+{
+	free_carry( c );
+	int r = 0;
+	for (int k = 0; k < 2 && !r; k++)
+		r = dev_alloc( c, &c->carry[k].o_t, c->carry_cap ) || dev_alloc( c, &c->carry[k].d_h, c->carry_cap ) || dev_alloc( c, &c->carry[k].T_s, c->carry_cap ) || dev_alloc( c, &c->carry[k].meta, c->carry_cap );
+	if (!r && hipMemset( c->carry_ctr, 0, sizeof( DevCounters ) ) != hipSuccess) r = RTMI_ERR_HIP;
+	return r ? RTMI_ERR_NOMEM : RTMI_OK;
+}
+static void free_left( BatchSlot& b )
+{
+	void* lp[] = { b.left.o_t, b.left.d_h, b.left.T_s, b.left.meta };
+	for (void* q : lp) if (q) (void)hipFree( q );
+	b.left = PathState{};
+}
+static int alloc_left( rtmi_ctx* c, BatchSlot& b )
+{
+	free_left( b );
+	if (dev_alloc( c, &b.left.o_t, c->left_cap ) || dev_alloc( c, &b.left.d_h, c->left_cap ) || dev_alloc( c, &b.left.T_s, c->left_cap ) || dev_alloc( c, &b.left.meta, c->left_cap )) return RTMI_ERR_NOMEM;
+	return hipMemset( b.n_left, 0, 4 ) == hipSuccess ? RTMI_OK : RTMI_ERR_HIP;
+}
+// streams, events, counters and the slot's list of left-over late paths; idempotent
+static int init_slot( rtmi_ctx* c, BatchSlot& b )
+{
+	if (b.ctr) return RTMI_OK;
+	if (dev_alloc( c, &b.ctr, 1 ) || hipHostMalloc( (void**)&b.host_counts, 4 * sizeof( uint32_t ), hipHostMallocMapped ) != hipSuccess ||
+		hipHostGetDevicePointer( (void**)&b.host_counts_dev, b.host_counts, 0 ) != hipSuccess) return RTMI_ERR_NOMEM;
+	// (a low-priority stream would suit the tails, but a run with hipStreamCreateWithPriority stopped making progress here)
+	bool ok = hipStreamCreateWithFlags( &b.tail_stream, hipStreamNonBlocking ) == hipSuccess;
+	for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags( &b.count_ev[i], hipEventDisableTiming ) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags( &b.bulk_done, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.acc_done, hipEventDisableTiming ) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags( &b.ev_shade, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.ev_any, hipEventDisableTiming ) == hipSuccess;
+	if (!ok) return RTMI_ERR_HIP;
+	(void)hipMemset( b.ctr, 0, sizeof( DevCounters ) );
+	if (dev_alloc( c, &b.n_left, 1 )) return RTMI_ERR_NOMEM;
+	return alloc_left( c, b );
+}
+static void set_max_blocks( rtmi_ctx* c )
+{
+	// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 4 (16 waves per CU).  The walk is bound by
+	// the memory system's random-access throughput, not by latency: measured on the 1M-triangle scene, 4 blocks per CU
+	// run the walks 8 % faster than 6 (fewer rays in flight share each XCD's 4 MiB L2), 3 as fast as 4, 2 as slow as 6.
+	const size_t per_block = (size_t)c->walk_depth * BLOCK * sizeof( uint32_t );
+	int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 4, ( 160 * 1024 ) / per_block ) );
+	if (c->blocks_per_cu_opt >= 1) per_cu = (int)std::min<size_t>( c->blocks_per_cu_opt, std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) ) );
+	c->max_blocks = c->n_cus * per_cu;
+}
+
+struct OptDesc { const char* key; long long lo, hi; };
+static const OptDesc g_opts[] = {
+	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "carry", 0, 1 }, { "tail_lanes", 1, 64 }, { "tail_waves", 1, 32 }, { "sblock", 256, 1024 },
+	{ "tail_block", 1, 16 }, { "tail_dense", 0, 1ll << 32 }, { "tail_mid", 0, 1ll << 32 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
+	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
+	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
+	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 1 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
+};
+// `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
+static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
+{
+	const OptDesc* d = 0;
+	for (const OptDesc& o : g_opts) if (!strcmp( o.key, key )) d = &o;
+	if (!d) return fail( c, RTMI_ERR_INVALID, std::string( "unknown option " ) + key );
+	if (v < d->lo || v > d->hi) return fail( c, RTMI_ERR_INVALID, std::string( "value out of range for option " ) + key );
+	auto is = [&]( const char* k ) { return !strcmp( key, k ); };
+	if (is( "log_bounces" )) c->log_bounces = v != 0;
+	else if (is( "overlap" )) c->overlap_on = v != 0 && c->side != 0;
+	else if (is( "wide" )) c->wide_on = v != 0;
+	else if (is( "carry" )) { c->carry_on = v != 0; if (!c->tail_paths_set) c->tail_paths = c->carry_on ? 1u << 22 : c->small_paths; }
+	else if (is( "tail_lanes" )) { if (v & ( v - 1 )) return fail( c, RTMI_ERR_INVALID, "tail_lanes must be a power of two" ); c->tail_lanes = (int)v; }
+	else if (is( "tail_waves" )) c->tail_waves = (int)v;
+	else if (is( "sblock" )) { if (v != 256 && v != 512 && v != 1024) return fail( c, RTMI_ERR_INVALID, "sblock must be 256, 512 or 1024" ); c->sblock = (int)v; }
+	else if (is( "tail_block" )) c->tail_block = (int)v;
+	else if (is( "tail_dense" )) c->tail_dense = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
+	else if (is( "tail_mid" )) c->tail_mid = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
+	else if (is( "tail_paths" )) c->tail_paths = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll ), c->tail_paths_set = true;
+	else if (is( "carry_bounce" )) c->carry_bounce = (int)v;
+	else if (is( "step_budget" )) c->budget = (int)v;
+	else if (is( "refill" )) c->refill = (int)v;
+	else if (is( "batch" )) c->batch_opt = (int)v;
+	else if (is( "grid_closest_hi" )) c->grid_closest[0] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
+	else if (is( "grid_closest_lo" )) c->grid_closest[1] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
+	else if (is( "grid_any_hi" )) c->grid_any[0] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
+	else if (is( "grid_any_lo" )) c->grid_any[1] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
+	else if (is( "check_launches" )) c->check_launches = v != 0;
+	else if (is( "hook_kernel" )) c->hook_kernel = (int)v;
+	else if (is( "tail_team" )) c->tail_team = v != 0;
+	else if (is( "tail_profile" )) c->tail_profile = v != 0;
+	else if (is( "team_below" )) c->team_below = (uint32_t)v;
+	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
+	else if (is( "slots" ))
+	{
+		c->n_slots = (int)v, c->next_slot = 0;
+		if (live) for (int k = 0; k < c->n_slots; k++) { int r = init_slot( c, c->slots[k] ); if (r) return r; }
+	}
+	else if (is( "carry_cap" ) || is( "left_cap" ))
+	{
+		( is( "carry_cap" ) ? c->carry_cap : c->left_cap ) = (uint32_t)v;
+		if (live)
+		{
+			free_batches( c ); // the queues of a batch are sized for the paths carried in
+			int r = is( "carry_cap" ) ? alloc_carry( c ) : RTMI_OK;
+			if (!r && is( "left_cap" )) for (auto& b : c->slots) if (b.ctr && !r) r = alloc_left( c, b );
+			if (r) return r;
+		}
+	}
+	return RTMI_OK;
+}
+static long long read_option( rtmi_ctx* c, const char* key, bool& found )
+{
+	auto is = [&]( const char* k ) { return !strcmp( key, k ); };
+	found = true;
+	if (is( "log_bounces" )) return c->log_bounces; if (is( "overlap" )) return c->overlap_on; if (is( "wide" )) return c->wide_on; if (is( "carry" )) return c->carry_on;
+	if (is( "tail_lanes" )) return c->tail_lanes; if (is( "tail_waves" )) return c->tail_waves; if (is( "sblock" )) return c->sblock; if (is( "tail_block" )) return c->tail_block;
+	if (is( "tail_dense" )) return c->tail_dense; if (is( "tail_mid" )) return c->tail_mid; if (is( "slots" )) return c->n_slots; if (is( "tail_paths" )) return c->tail_paths;
+	if (is( "carry_cap" )) return c->carry_cap; if (is( "left_cap" )) return c->left_cap; if (is( "carry_bounce" )) return c->carry_bounce; if (is( "step_budget" )) return c->budget;
+	if (is( "refill" )) return c->refill; if (is( "batch" )) return c->batch_opt; if (is( "blocks_per_cu" )) return c->blocks_per_cu_opt;
+	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
+	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
+	if (is( "team_below" )) return c->team_below;
+	found = false;
+	return 0;
 }
 
 extern "C" {
 
-const char* rtmi_version( void ) { return "rtmi 0.1 (gfx950)"; }
+const char* rtmi_version( void ) { return "rtmi 0.2 (gfx950)"; }
 const char* rtmi_last_error( rtmi_ctx* c ) { return c ? c->err.c_str() : "null context"; }
 
 int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
@@ -1421,48 +1800,30 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties( &prop, device_id ) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-		c->log_bounces = getenv( "RTMI_LOG_BOUNCES" ) != 0;
+		if (hipStreamCreateWithFlags( &c->side, hipStreamNonBlocking ) != hipSuccess) c->overlap_on = false, c->side = 0;
+		const uint32_t lanes = (uint32_t)c->n_cus * 1024u; // 4 blocks of 256 per CU
+		c->grid_closest[0] = 61u * lanes, c->grid_closest[1] = 19u * lanes, c->grid_any[0] = 76u * lanes, c->grid_any[1] = 30u * lanes;
+		c->tail_paths = 1u << 22;
 		// batches in flight: each uses its own stream, and streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES,
 		// 4 unless the process raises it before HIP starts) serialise behind each other
-		const char* q = getenv( "GPU_MAX_HW_QUEUES" );
-		if (getenv( "RTMI_OVERLAP" )) c->overlap_on = atoi( getenv( "RTMI_OVERLAP" ) ) != 0;
-		if (c->overlap_on && hipStreamCreateWithFlags( &c->side, hipStreamNonBlocking ) != hipSuccess) c->overlap_on = false, c->side = 0;
+		// defaults from the environment (RTMI_<KEY>, upper case); a bad value is ignored with a note, not fatal
+		for (const OptDesc& o : g_opts)
 		{
-			const uint32_t lanes = (uint32_t)c->n_cus * 1024u; // 4 blocks of 256 per CU
-			c->grid_closest[0] = 61u * lanes, c->grid_closest[1] = 19u * lanes, c->grid_any[0] = 76u * lanes, c->grid_any[1] = 30u * lanes;
+			std::string name = "RTMI_";
+			for (const char* k = o.key; *k; k++) name += (char)toupper( *k );
+			const char* e = getenv( name.c_str() );
+			if (!e) continue;
+			const long long v = *e ? atoll( e ) : 1;
+			if (apply_option( c, o.key, v, false ) != RTMI_OK) fprintf( stderr, "rtmi_create: ignoring %s=%s (%s)\n", name.c_str(), e, c->err.c_str() ), c->err.clear();
 		}
+		// earlier spellings of three of them
 		if (getenv( "RTMI_GRID_CLOSEST" )) sscanf( getenv( "RTMI_GRID_CLOSEST" ), "%u,%u", &c->grid_closest[0], &c->grid_closest[1] );
 		if (getenv( "RTMI_GRID_ANY" )) sscanf( getenv( "RTMI_GRID_ANY" ), "%u,%u", &c->grid_any[0], &c->grid_any[1] );
-		if (getenv( "RTMI_WIDE" )) c->wide_on = atoi( getenv( "RTMI_WIDE" ) ) != 0;
-		if (getenv( "RTMI_CARRY" )) c->carry_on = atoi( getenv( "RTMI_CARRY" ) ) != 0;
-		c->n_slots = c->carry_on || !q || atoi( q ) < 7 ? 4 : atoi( q ) >= 13 ? 12 : 6; // whole tails (RTMI_CARRY=0) last 0.5 s: more batches in flight
-		const char* e = getenv( "RTMI_TAIL_LANES" );
-		if (e) { const int v = atoi( e ); if (v >= 1 && v <= 64 && ( v & ( v - 1 ) ) == 0) c->tail_lanes = v; }
-		e = getenv( "RTMI_TAIL_WAVES" );
-		if (e && atoi( e ) >= 1 && atoi( e ) <= 32) c->tail_waves = atoi( e );
-		e = getenv( "RTMI_SBLOCK" );
-		if (e && ( atoi( e ) == 256 || atoi( e ) == 512 || atoi( e ) == 1024 )) c->sblock = atoi( e );
-		e = getenv( "RTMI_TAIL_BLOCK" );
-		if (e && atoi( e ) >= 1 && atoi( e ) <= 16) c->tail_block = atoi( e );
-		e = getenv( "RTMI_TAIL_DENSE" );
-		if (e && atoll( e ) >= 0) c->tail_dense = (uint32_t)atoll( e );
-		e = getenv( "RTMI_TAIL_MID" );
-		if (e && atoll( e ) >= 0) c->tail_mid = (uint32_t)atoll( e );
-		e = getenv( "RTMI_SLOTS" );
-		if (e && atoi( e ) >= 1 && atoi( e ) <= MAX_SLOTS) c->n_slots = atoi( e );
-		c->tail_paths = c->carry_on ? 1u << 22 : c->small_paths;
-		e = getenv( "RTMI_TAIL_PATHS" );
-		if (e && atoll( e ) >= 0) c->tail_paths = (uint32_t)atoll( e );
-		e = getenv( "RTMI_CARRY_CAP" ); // (tests: small buffers exercise the paths taken when they are full)
-		if (e && atoll( e ) >= 1 && atoll( e ) <= ( 1ll << 24 )) c->carry_cap = (uint32_t)atoll( e );
-		e = getenv( "RTMI_LEFT_CAP" );
-		if (e && atoll( e ) >= 1 && atoll( e ) <= ( 1ll << 20 )) c->left_cap = (uint32_t)atoll( e );
-		e = getenv( "RTMI_CARRY_BOUNCE" );
-		if (e && atoi( e ) >= 0) c->carry_bounce = atoi( e );
-		e = getenv( "RTMI_STEP_BUDGET" );
-		if (e && atoi( e ) >= 0) c->budget = atoi( e );
-		e = getenv( "RTMI_REFILL" );
-		if (e && atoi( e ) >= 1 && atoi( e ) <= 64) c->refill = atoi( e );
+		if (!getenv( "RTMI_SLOTS" ))
+		{
+			const char* q = getenv( "GPU_MAX_HW_QUEUES" );
+			c->n_slots = c->carry_on || !q || atoi( q ) < 7 ? 4 : atoi( q ) >= 13 ? 12 : 6; // whole tails (carry = 0) last 0.5 s: more batches in flight
+		}
 	}
 	const size_t n = (size_t)width * height;
 	if (dev_alloc( c, &c->seeds, n ) || dev_alloc( c, &c->accum_own, n ) || dev_alloc( c, &c->pixels, n ) || dev_alloc( c, &c->pixels2, n ) ||
@@ -1471,29 +1832,13 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	if (hipHostMalloc( (void**)&c->draining, 64, hipHostMallocMapped ) != hipSuccess || hipHostGetDevicePointer( (void**)&c->draining_dev, c->draining, 0 ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
 	*c->draining = 0;
 	{
-		int r = dev_alloc( c, &c->late, 4 * n ) || dev_alloc( c, &c->carry_ctr, 1 );
-		for (int k = 0; k < 2 && !r; k++)
-			r = dev_alloc( c, &c->carry[k].o_t, c->carry_cap ) || dev_alloc( c, &c->carry[k].d_h, c->carry_cap ) || dev_alloc( c, &c->carry[k].T_s, c->carry_cap ) || dev_alloc( c, &c->carry[k].meta, c->carry_cap );
+		int r = dev_alloc( c, &c->late, 4 * n ) || dev_alloc( c, &c->odd, n ) || dev_alloc( c, &c->carry_ctr, 1 );
+		if (!r) r = alloc_carry( c );
 		if (r) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
 		(void)hipMemset( c->late, 0, 4 * n * sizeof( long long ) );
-		(void)hipMemset( c->carry_ctr, 0, sizeof( DevCounters ) );
+		(void)hipMemset( c->odd, 0, n * sizeof( float4 ) );
 	}
-	for (int k = 0; k < c->n_slots; k++)
-	{
-		BatchSlot& b = c->slots[k];
-		if (dev_alloc( c, &b.ctr, 1 ) || hipHostMalloc( (void**)&b.host_counts, 4 * sizeof( uint32_t ), hipHostMallocMapped ) != hipSuccess ||
-			hipHostGetDevicePointer( (void**)&b.host_counts_dev, b.host_counts, 0 ) != hipSuccess) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
-		// (a low-priority stream would suit the tails, but a run with hipStreamCreateWithPriority stopped making progress here)
-		bool ok = hipStreamCreateWithFlags( &b.tail_stream, hipStreamNonBlocking ) == hipSuccess;
-		for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags( &b.count_ev[i], hipEventDisableTiming ) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags( &b.bulk_done, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.acc_done, hipEventDisableTiming ) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags( &b.ev_shade, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.ev_any, hipEventDisableTiming ) == hipSuccess;
-		if (!ok) { rtmi_destroy( c ); return RTMI_ERR_HIP; }
-		(void)hipMemset( b.ctr, 0, sizeof( DevCounters ) );
-		if (dev_alloc( c, &b.left.o_t, c->left_cap ) || dev_alloc( c, &b.left.d_h, c->left_cap ) || dev_alloc( c, &b.left.T_s, c->left_cap ) || dev_alloc( c, &b.left.meta, c->left_cap ) ||
-			dev_alloc( c, &b.n_left, 1 )) { rtmi_destroy( c ); return RTMI_ERR_NOMEM; }
-		(void)hipMemset( b.n_left, 0, 4 );
-	}
+	for (int k = 0; k < c->n_slots; k++) { int r = init_slot( c, c->slots[k] ); if (r) { rtmi_destroy( c ); return r; } }
 	(void)hipMemset( c->accum_own, 0, n * sizeof( float4 ) );
 	(void)hipMemset( c->seeds, 0, n * sizeof( uint32_t ) );
 	// default camera, camera.h:20-23
@@ -1509,15 +1854,14 @@ int rtmi_destroy( rtmi_ctx* c )
 	(void)hipSetDevice( c->device );
 	(void)hipDeviceSynchronize();
 	resolve_timers( c );
-	free_scene( c ), free_batches( c );
-	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->frames, c->late, c->carry_ctr,
-		c->carry[0].o_t, c->carry[0].d_h, c->carry[0].T_s, c->carry[0].meta, c->carry[1].o_t, c->carry[1].d_h, c->carry[1].T_s, c->carry[1].meta };
+	free_scene( c ), free_batches( c ), free_carry( c );
+	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->frames, c->late, c->odd, c->carry_ctr, c->hook_buf };
 	for (void* p : ps) if (p) (void)hipFree( p );
 	for (auto& b : c->slots)
 	{
 		if (b.ctr) (void)hipFree( b.ctr );
-		void* lp[] = { b.left.o_t, b.left.d_h, b.left.T_s, b.left.meta, b.n_left };
-		for (void* q : lp) if (q) (void)hipFree( q );
+		free_left( b );
+		if (b.n_left) (void)hipFree( b.n_left );
 		if (b.host_counts) (void)hipHostFree( b.host_counts );
 		for (int i = 0; i < 4; i++) if (b.count_ev[i]) (void)hipEventDestroy( b.count_ev[i] );
 		if (b.bulk_done) (void)hipEventDestroy( b.bulk_done );
@@ -1534,12 +1878,41 @@ int rtmi_destroy( rtmi_ctx* c )
 	return RTMI_OK;
 }
 
+int rtmi_set_option( rtmi_ctx* c, const char* key, long long value )
+{
+	if (!c || !key) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; } // what is in flight finishes under the settings it was started with
+	{ int r = sync_all( c ); if (r) return r; }
+	return apply_option( c, key, value, true );
+}
+int rtmi_get_option( rtmi_ctx* c, const char* key, long long* value_out )
+{
+	if (!c || !key || !value_out) return RTMI_ERR_INVALID;
+	bool found;
+	*value_out = read_option( c, key, found );
+	return found ? RTMI_OK : fail( c, RTMI_ERR_INVALID, std::string( "unknown option " ) + key );
+}
+
+// the value is the stream: NULL is HIP's null stream (a torch process that never leaves its default stream passes 0 here)
 int rtmi_set_stream( rtmi_ctx* c, void* s )
 {
 	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; }
 	int r = sync_all( c );
 	if (r) return r;
-	c->stream = s ? (hipStream_t)s : c->own_stream;
+	c->stream = (hipStream_t)s;
+	return RTMI_OK;
+}
+int rtmi_use_own_stream( rtmi_ctx* c )
+{
+	if (!c) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	{ int r = join_batches( c ); if (r) return r; }
+	int r = sync_all( c );
+	if (r) return r;
+	c->stream = c->own_stream;
 	return RTMI_OK;
 }
 
@@ -1694,26 +2067,43 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 		const int nn = d->n_nodes;
 		if (( nn - 3 ) % 2 != 0) return fail( c, RTMI_ERR_BVH, "n_nodes must be 3 + 2*pairs" );
 		const int npairs = ( nn - 3 ) / 2;
+		std::vector<float4> pairs( (size_t)( npairs > 0 ? npairs : 1 ) * 4, make_float4( 0, 0, 0, 0 ) );
+		// A leaf reference holds count - 1 in 6 bits.  The reference's builder stops splitting whenever no split lowers the SAH
+		// cost (bvh.h:344), so coincident or degenerate geometry gives leaves of any size, which its traversal walks like any
+		// other (bvh.h:513-523).  Such a leaf becomes a small balanced subtree of synthetic pairs appended behind the real ones:
+		// every synthetic child carries the LEAF'S OWN box and the chunks cover its primitives in order, 64 at a time, so box
+		// tests, primitive order and the (t, position) rule are what they were.
+		std::function<uint32_t( int, int, const rtmi_bvh_node& )> chunked = [&]( int first, int count, const rtmi_bvh_node& n ) -> uint32_t {
+			if (count <= RT_LEAF_MAX_COUNT) return RT_LEAF | ( (uint32_t)( count - 1 ) << RT_LEAF_FIRST_BITS ) | (uint32_t)first;
+			const int chunks = ( count + RT_LEAF_MAX_COUNT - 1 ) / RT_LEAF_MAX_COUNT, lc = ( chunks / 2 ) * RT_LEAF_MAX_COUNT;
+			const size_t idx = pairs.size() / 4;
+			pairs.resize( pairs.size() + 4, make_float4( 0, 0, 0, 0 ) );
+			const uint32_t rl = chunked( first, lc, n ), rr = chunked( first + lc, count - lc, n );
+			const int cl = lc, cr = count - lc;
+			float4 q1 = make_float4( n.aabbMaxy, n.aabbMaxz, 0, 0 ), q3 = q1;
+			memcpy( &q1.z, &rl, 4 ), memcpy( &q1.w, &cl, 4 ), memcpy( &q3.z, &rr, 4 ), memcpy( &q3.w, &cr, 4 );
+			pairs[4 * idx] = pairs[4 * idx + 2] = make_float4( n.aabbMinx, n.aabbMiny, n.aabbMinz, n.aabbMaxx );
+			pairs[4 * idx + 1] = q1, pairs[4 * idx + 3] = q3;
+			return (uint32_t)idx; };
 		auto encode = [&]( const rtmi_bvh_node& n, uint32_t& ref ) -> bool {
 			if (n.primitiveCount > 0)
 			{
-				if (n.primitiveCount > RT_LEAF_MAX_COUNT || n.leftFirst < 0 || (long long)n.leftFirst + n.primitiveCount > nbvh) return false;
-				ref = RT_LEAF | ( (uint32_t)( n.primitiveCount - 1 ) << RT_LEAF_FIRST_BITS ) | (uint32_t)n.leftFirst;
+				if (n.leftFirst < 0 || (long long)n.leftFirst + n.primitiveCount > nbvh) return false;
+				ref = chunked( n.leftFirst, n.primitiveCount, n );
 				return true;
 			}
 			if (n.primitiveCount < 0 || n.leftFirst < 3 || n.leftFirst + 1 >= nn || ( ( n.leftFirst - 3 ) & 1 )) return false;
 			ref = (uint32_t)( ( n.leftFirst - 3 ) / 2 );
 			return true; };
 		const rtmi_bvh_node& root = d->nodes[2];
-		if (!encode( root, ds.root_ref )) return fail( c, RTMI_ERR_BVH, "bad root node (leaf larger than 64 primitives or index out of range)" );
+		if (!encode( root, ds.root_ref )) return fail( c, RTMI_ERR_BVH, "bad root node (index or primitive range out of bounds)" );
 		ds.root_min[0] = root.aabbMinx, ds.root_min[1] = root.aabbMiny, ds.root_min[2] = root.aabbMinz;
 		ds.root_max[0] = root.aabbMaxx, ds.root_max[1] = root.aabbMaxy, ds.root_max[2] = root.aabbMaxz;
-		std::vector<float4> pairs( (size_t)( npairs > 0 ? npairs : 1 ) * 4, make_float4( 0, 0, 0, 0 ) );
 		for (int k = 0; k < npairs; k++)
 		{
 			const rtmi_bvh_node& L = d->nodes[3 + 2 * k], &R = d->nodes[4 + 2 * k];
 			uint32_t rl, rr;
-			if (!encode( L, rl ) || !encode( R, rr )) return fail( c, RTMI_ERR_BVH, "bad node (leaf larger than 64 primitives or index out of range)" );
+			if (!encode( L, rl ) || !encode( R, rr )) return fail( c, RTMI_ERR_BVH, "bad node (index or primitive range out of bounds)" );
 			pairs[4 * (size_t)k + 0] = make_float4( L.aabbMinx, L.aabbMiny, L.aabbMinz, L.aabbMaxx );
 			float4 q1 = make_float4( L.aabbMaxy, L.aabbMaxz, 0, 0 ); memcpy( &q1.z, &rl, 4 ); memcpy( &q1.w, &L.primitiveCount, 4 );
 			pairs[4 * (size_t)k + 1] = q1;
@@ -1723,7 +2113,8 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 		}
 		// walk the tree: every pair reachable exactly once (no cycles / sharing), depth bound for the traversal stack
 		{
-			std::vector<uint8_t> seen( npairs > 0 ? npairs : 1, 0 );
+			const size_t allPairs = pairs.size() / 4; // the reference's pairs and the synthetic ones
+			std::vector<uint8_t> seen( allPairs, 0 );
 			std::vector<std::pair<uint32_t, int>> stk;
 			if (!( ds.root_ref & RT_LEAF )) stk.push_back( { ds.root_ref, 1 } );
 			size_t visited = 0;
@@ -1731,7 +2122,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 			{
 				auto [p, dep] = stk.back();
 				stk.pop_back();
-				if (p >= (uint32_t)npairs || seen[p]) return fail( c, RTMI_ERR_BVH, "node array is not a tree" );
+				if (p >= allPairs || seen[p]) return fail( c, RTMI_ERR_BVH, "node array is not a tree" );
 				seen[p] = 1, visited++;
 				maxDepth = std::max( maxDepth, dep );
 				uint32_t rl, rr;
@@ -1852,16 +2243,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
 	c->walk_depth = std::max( c->stack_depth, wideNeed + 1 );
-	{
-		// blocks that stay resident per CU: 160 KiB LDS / per-block stack, at most 4 (16 waves per CU).  The walk is bound by
-		// the memory system's random-access throughput, not by latency: measured on the 1M-triangle scene, 4 blocks per CU
-		// run the walks 8 % faster than 6 (fewer rays in flight share each XCD's 4 MiB L2), 3 as fast as 4, 2 as slow as 6.
-		const size_t per_block = (size_t)c->walk_depth * BLOCK * sizeof( uint32_t );
-		int per_cu = (int)std::max<size_t>( 1, std::min<size_t>( 4, ( 160 * 1024 ) / per_block ) );
-		const char* e = getenv( "RTMI_BLOCKS_PER_CU" );
-		if (e && atoi( e ) >= 1) per_cu = (int)std::min<size_t>( atoi( e ), std::max<size_t>( 1, std::min<size_t>( 8, ( 160 * 1024 ) / per_block ) ) );
-		c->max_blocks = c->n_cus * per_cu;
-	}
+	set_max_blocks( c );
 	return RTMI_OK;
 }
 
@@ -1898,6 +2280,18 @@ int rtmi_set_accumulator( rtmi_ctx* c, void* p )
 }
 
 static size_t stack_bytes( rtmi_ctx* c ) { return (size_t)c->stack_depth * BLOCK * sizeof( uint32_t ); }
+// device scratch of the parity hooks and rtmi_postprocess: kept in the handle, grown when a call needs more
+static int hook_reserve( rtmi_ctx* c, size_t bytes )
+{
+	if (c->hook_cap >= bytes) return RTMI_OK;
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	if (c->hook_buf) (void)hipFree( c->hook_buf ), c->hook_buf = 0, c->hook_cap = 0;
+	const size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~(size_t)( ( 1u << 20 ) - 1 );
+	hipError_t e = hipMalloc( &c->hook_buf, want );
+	if (e != hipSuccess) { c->hook_buf = 0; c->err = std::string( "hipMalloc: " ) + hipGetErrorString( e ); return RTMI_ERR_NOMEM; }
+	c->hook_cap = want;
+	return RTMI_OK;
+}
 
 static inline int nsblocks( rtmi_ctx* c, size_t n ) { return (int)( ( n + c->sblock - 1 ) / c->sblock ); }
 // persistent launches: as many blocks as stay resident (LDS stack bound), never more than the rays need.
@@ -1942,7 +2336,7 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 }
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
 {
-	ScopedTimer t( c, 1 );
+	ScopedTimer t( c, 1, c->stream );
 	hipLaunchKernelGGL( k_primary, dim3( nsblocks( c, N ) ), dim3( c->sblock ), 0, c->stream, c->ds, b.st[0], b.E, (float4*)b.Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
 		c->seeds, sample_begin, stride, b.wq[0], b.ctr );
 }
@@ -1984,7 +2378,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	int clean = 0;      // consecutive bounces launched without parking
 	bool tail = false, side_busy = false;
 	hipEvent_t window = 0; // (profiling) open walk window: from the end of a k_shade to the point where both walks after it are done
-	auto close_window = [&]() { if (window) { hipEvent_t e = get_event( c ); (void)hipEventRecord( e, s ); c->timed.push_back( { window, e, 4 } ); window = 0; } };
+	auto close_window = [&]() { if (window) { hipEvent_t e = get_event( c ); if (e) { (void)hipEventRecord( e, s ); c->timed.push_back( { window, e, 4 } ); } else c->ev_pool.push_back( window ); window = 0; } };
 	const int min_bounce = c->carry_on && !last ? c->carry_bounce : 0; // with carry, a batch that is still large stays in the loop until its paths are late
 	const uint32_t tail_paths = last ? c->small_paths : c->tail_paths;
 	for (int bounce = 0;; bounce++)
@@ -1998,12 +2392,12 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		if (tail_paths && clean >= 1 && ( ( upper <= tail_paths && bounce >= min_bounce ) || upper <= c->small_paths )) { tail = true; break; }
 		const int budget = prep ? 0 : c->budget;
 		clean = prep ? clean + 1 : 0;
-		if (bounce == 0 && c->overlap_on && c->prof_events) { window = get_event( c ); (void)hipEventRecord( window, s ); } // the first walk has a window to itself
+		if (bounce == 0 && c->overlap_on && c->prof_events) { window = get_event( c ); if (window) (void)hipEventRecord( window, s ); } // the first walk has a window to itself
 		launch_trace( c, b, false, cur, upper, budget );
 		if (side_busy) { HIPCHK( hipStreamWaitEvent( s, b.ev_any, 0 ) ); side_busy = false; } // the previous bounce's shadow walk fills the queue k_shade appends to
 		close_window();
 		{
-			ScopedTimer t( c, 1 );
+			ScopedTimer t( c, 1, c->stream );
 			hipLaunchKernelGGL( k_shade, dim3( nsblocks( c, upper ) ), dim3( c->sblock ), 0, s, c->ds, b.st[cur], b.st[cur ^ 1], b.sq[cur], make_sinks( c, b ), &ctr->n_state[cur], &ctr->n_state[cur ^ 1],
 				b.wq[cur ^ 1], &ctr->n_walk[cur ^ 1], &ctr->n_shadow[cur], ctr );
 		}
@@ -2022,7 +2416,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			HIPCHK( hipEventRecord( b.ev_any, c->side ) );
 			side_busy = true;
 			hipLaunchKernelGGL( k_next_bounce_pre, dim3( 1 ), dim3( 1 ), 0, s, ctr, cur );
-			if (c->prof_events) { window = get_event( c ); (void)hipEventRecord( window, s ); }
+			if (c->prof_events) { window = get_event( c ); if (window) (void)hipEventRecord( window, s ); }
 		}
 		else
 		{
@@ -2032,6 +2426,12 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		}
 		c->stats.bounce_launches++;
 		cur ^= 1;
+		HIPCHK( hipGetLastError() ); // a launch that was refused (bad configuration) is reported for the bounce it belongs to
+		if (c->check_launches) // diagnostics: a fault inside a kernel surfaces here, at its bounce, instead of at the next read
+		{
+			HIPCHK( hipStreamSynchronize( s ) );
+			if (c->side) HIPCHK( hipStreamSynchronize( c->side ) );
+		}
 		if (bounce >= 2)
 		{
 			const int old = ( bounce - 2 ) & 3;
@@ -2096,16 +2496,18 @@ static int fetch_counters( rtmi_ctx* c )
 {
 	int r = sync_all( c );
 	if (r) return r;
-	for (int k = 0; k <= c->n_slots; k++)
+	for (int k = 0; k <= MAX_SLOTS; k++)
 	{
 		DevCounters h;
-		DevCounters* src = k < c->n_slots ? c->slots[k].ctr : c->carry_ctr;
+		DevCounters* src = k < MAX_SLOTS ? c->slots[k].ctr : c->carry_ctr; // every slot that was ever set up (option slots may have shrunk)
+		if (!src) continue;
 		HIPCHK( hipMemcpy( &h, src, sizeof( h ), hipMemcpyDeviceToHost ) );
 		c->stats.extend_rays += h.extend_rays, c->stats.shadow_rays += h.shadow_rays;
 		c->stats.extend_pairs += h.extend_pairs, c->stats.extend_prims += h.extend_prims;
 		c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
 		c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
 		c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
+		for (int i = 0; i < 8; i++) c->stats.tail_profile[i] += h.tail_prof[i];
 		// the ray counters only: the queue lengths of the carry buffer stay
 		HIPCHK( hipMemset( (char*)src + offsetof( DevCounters, extend_rays ), 0, sizeof( DevCounters ) - offsetof( DevCounters, extend_rays ) ) );
 	}
@@ -2124,8 +2526,7 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		*(volatile uint32_t*)c->draining = 0; // more bulk work is coming: the tails in flight run for throughput again
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
 		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
-		const char* env = getenv( "RTMI_BATCH" );
-		if (env && atoi( env ) > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, atoi( env ) ), ( 1ll << 25 ) / WH ) );
+		if (c->batch_opt > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, c->batch_opt ), ( 1ll << 25 ) / WH ) );
 		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
 		for (int k = 0; k < c->n_slots; k++) { int r = ensure_batch( c, c->slots[k], S ); if (r) return r; }
 		for (int done = 0; done < sample_count; done += S)
@@ -2151,7 +2552,7 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		c->frames_depth = max_depth;
 	}
 	{
-		ScopedTimer t( c, 3 );
+		ScopedTimer t( c, 3, c->stream );
 		hipLaunchKernelGGL( k_whitted, dim3( nblocks( WH ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, mode, max_depth,
 			anti_aliasing, c->frames, c->accum );
 	}
@@ -2169,9 +2570,8 @@ int rtmi_trace_primary( rtmi_ctx* c, int32_t* obj_out, float* t_out )
 	if (r) return r;
 	if (b.busy) { HIPCHK( hipStreamWaitEvent( c->stream, b.acc_done, 0 ) ); b.busy = false; }
 	const int WH = c->W * c->H;
-	int* dobj = 0; float* dt = 0;
-	if (( r = dev_alloc( c, &dobj, WH ) )) return r;
-	if (( r = dev_alloc( c, &dt, WH ) )) { (void)hipFree( dobj ); return r; }
+	if (( r = hook_reserve( c, (size_t)WH * 8 ) )) return r;
+	int* dobj = (int*)c->hook_buf; float* dt = (float*)c->hook_buf + WH;
 	hipError_t e0 = hipMemsetAsync( b.ctr, 0, 64, c->stream );
 	launch_primary( c, b, (uint32_t)WH, 0, 1 );
 	launch_trace( c, b, false, 0, (uint32_t)WH, 0 ); // no step budget: every ray finishes in this launch
@@ -2179,8 +2579,32 @@ int rtmi_trace_primary( rtmi_ctx* c, int32_t* obj_out, float* t_out )
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)WH * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e3 = hipStreamSynchronize( c->stream );
-	(void)hipFree( dobj ), (void)hipFree( dt );
 	HIPCHK( e0 ); HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
+	HIPCHK( hipGetLastError() );
+	return RTMI_OK;
+}
+
+// the kernels of rtmi_trace_rays over rays that are already on the device (shared with rtmi_trace_rays_noalloc)
+static int launch_trace_rays( rtmi_ctx* c, int n, const float* dO, const float* dD, const float* dT, int any_hit, int* dobj, float* dt )
+{
+	if (c->hook_kernel == 0)
+	{
+		hipLaunchKernelGGL( k_trace_rays, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+		HIPCHK( hipGetLastError() );
+		return RTMI_OK;
+	}
+	const size_t WH = (size_t)c->W * c->H;
+	if ((size_t)n > ( 1u << 25 )) return fail( c, RTMI_ERR_INVALID, "hook_kernel = 1: at most 2^25 rays per call" );
+	BatchSlot& b = c->slots[0];
+	int r = ensure_batch( c, b, (int)( ( (size_t)n + WH - 1 ) / WH ) );
+	if (r) return r;
+	if (b.busy) { HIPCHK( hipStreamWaitEvent( c->stream, b.acc_done, 0 ) ); b.busy = false; }
+	HIPCHK( hipMemsetAsync( b.ctr, 0, 64, c->stream ) );
+	hipLaunchKernelGGL( k_rays_begin, dim3( nsblocks( c, (size_t)n ) ), dim3( c->sblock ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, b.st[0], b.sq[0], (float4*)b.Es, b.wq[0], dobj, dt, b.ctr );
+	launch_trace( c, b, any_hit != 0, 0, (uint32_t)n, 0 ); // no step budget: every ray finishes in this launch
+	if (any_hit) hipLaunchKernelGGL( k_rays_any_result, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, b.Es, n, dobj );
+	else hipLaunchKernelGGL( k_copy_hits, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, b.st[0], n, dobj, dt );
+	HIPCHK( hipGetLastError() );
 	return RTMI_OK;
 }
 
@@ -2190,17 +2614,17 @@ int rtmi_trace_rays( rtmi_ctx* c, int n, const float* O3, const float* D3, const
 	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_trace_rays before rtmi_upload_scene" );
 	if (n == 0) return RTMI_OK;
 	HIPCHK( hipSetDevice( c->device ) );
-	std::vector<void*> tmp;
-	float* dO = 0, *dD = 0, *dT = 0, *dt = 0; int* dobj = 0;
-	int r;
-	auto cleanup = [&]() { for (void* p : tmp) (void)hipFree( p ); };
-	if (( r = dev_upload( c, &dO, O3, (size_t)n * 3, &tmp ) ) || ( r = dev_upload( c, &dD, D3, (size_t)n * 3, &tmp ) ) || ( r = dev_upload( c, &dT, tmax, (size_t)n, &tmp ) ) ||
-		( r = dev_alloc( c, &dt, (size_t)n, &tmp ) ) || ( r = dev_alloc( c, &dobj, (size_t)n, &tmp ) )) { cleanup(); return r; }
-	hipLaunchKernelGGL( k_trace_rays, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+	int r = hook_reserve( c, (size_t)n * 9 * 4 );
+	if (r) return r;
+	float* dO = (float*)c->hook_buf, *dD = dO + 3 * (size_t)n, *dT = dD + 3 * (size_t)n, *dt = dT + n;
+	int* dobj = (int*)( dt + n );
+	HIPCHK( hipMemcpyAsync( dO, O3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dD, D3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dT, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream ) );
+	if (( r = launch_trace_rays( c, n, dO, dD, dT, any_hit, dobj, dt ) )) return r;
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e3 = hipStreamSynchronize( c->stream );
-	cleanup();
 	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
 	return RTMI_OK;
 }
@@ -2211,11 +2635,14 @@ static int run_postfx( rtmi_ctx* c, uint32_t* px, uint32_t* tmp, int W, int H, c
 	if (fx->gamma_on)
 	{
 		// GammaCorrection, postprocessing.h:78-99
-		uint32_t lut[256];
-		const float gc = 1.0f / fx->gamma;
-		for (int i = 0; i < 256; i++) lut[i] = (uint32_t)( 255.0f * powf( (float)i / 255.0f, gc ) ) & 255u;
-		HIPCHK( hipMemcpyAsync( c->gamma_lut, lut, sizeof( lut ), hipMemcpyHostToDevice, c->stream ) );
-		HIPCHK( hipStreamSynchronize( c->stream ) ); // lut is on the stack
+		if (c->gamma_cached != fx->gamma) // the table lives in the handle: no host wait for a stack copy, no re-upload per frame
+		{
+			const float gc = 1.0f / fx->gamma;
+			HIPCHK( hipStreamSynchronize( c->stream ) ); // a copy of the previous table may still be reading gamma_host
+			for (int i = 0; i < 256; i++) c->gamma_host[i] = (uint32_t)( 255.0f * powf( (float)i / 255.0f, gc ) ) & 255u;
+			HIPCHK( hipMemcpyAsync( c->gamma_lut, c->gamma_host, sizeof( c->gamma_host ), hipMemcpyHostToDevice, c->stream ) );
+			c->gamma_cached = fx->gamma;
+		}
 		hipLaunchKernelGGL( k_gamma, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, px, n, c->gamma_lut );
 	}
 	if (fx->chroma_on)
@@ -2235,12 +2662,13 @@ int rtmi_finalize( rtmi_ctx* c, uint32_t* out, int frames, const rtmi_postfx* fx
 	{ int r = join_batches( c ); if (r) return r; }
 	const int n = c->W * c->H;
 	{
-		ScopedTimer t( c, 3 );
+		ScopedTimer t( c, 3, c->stream );
 		hipLaunchKernelGGL( k_finalize, dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->pixels, n, frames );
 	}
 	if (fx) { int r = run_postfx( c, c->pixels, c->pixels2, c->W, c->H, fx ); if (r) return r; }
 	HIPCHK( hipMemcpyAsync( out, c->pixels, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
+	drain_closed( c );
 	return RTMI_OK;
 }
 
@@ -2249,15 +2677,13 @@ int rtmi_postprocess( rtmi_ctx* c, uint32_t* px, int W, int H, const rtmi_postfx
 	if (!c || !px || !fx || W <= 0 || H <= 0) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
 	const size_t n = (size_t)W * H;
-	uint32_t* a = 0, *b = 0;
-	int r;
-	if (( r = dev_alloc( c, &a, n ) )) return r;
-	if (( r = dev_alloc( c, &b, n ) )) { (void)hipFree( a ); return r; }
+	int r = hook_reserve( c, n * 8 );
+	if (r) return r;
+	uint32_t* a = (uint32_t*)c->hook_buf, *b = a + n;
 	hipError_t e = hipMemcpyAsync( a, px, n * 4, hipMemcpyHostToDevice, c->stream );
 	if (e == hipSuccess) r = run_postfx( c, a, b, W, H, fx );
 	if (e == hipSuccess && !r) e = hipMemcpyAsync( px, a, n * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipStreamSynchronize( c->stream );
-	(void)hipFree( a ), (void)hipFree( b );
 	if (r) return r;
 	HIPCHK( e ); HIPCHK( e2 );
 	return RTMI_OK;
@@ -2270,6 +2696,40 @@ int rtmi_read_accumulator( rtmi_ctx* c, float* out )
 	{ int r = join_batches( c ); if (r) return r; }
 	HIPCHK( hipMemcpyAsync( out, c->accum, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
+	drain_closed( c );
+	return RTMI_OK;
+}
+
+// ---- multi-GPU inside the boundary: one RCCL reduce of the float4 accumulators ---------------------------------
+// librccl is bound at first use with dlopen/dlsym so that librtmi.so neither needs it at load time nor brings a second copy
+// into a process that already has one (torch ships its own librccl.so.1: the same SONAME resolves to the loaded copy).
+typedef int ( *rccl_reduce_fn )( const void*, void*, size_t, int, int, int, void*, hipStream_t );
+typedef int ( *rccl_allreduce_fn )( const void*, void*, size_t, int, int, void*, hipStream_t );
+typedef const char* ( *rccl_errstr_fn )( int );
+static struct { std::once_flag once; rccl_reduce_fn reduce = 0; rccl_allreduce_fn allreduce = 0; rccl_errstr_fn errstr = 0; std::string how; } g_rccl;
+static void bind_rccl()
+{
+	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	void* h = 0;
+	for (const char* n : names) if (!h) h = dlopen( n, RTLD_NOW | RTLD_NOLOAD ); // a copy the process already loaded
+	for (const char* n : names) if (!h) h = dlopen( n, RTLD_NOW | RTLD_LOCAL );
+	if (!h) { g_rccl.how = std::string( "cannot load librccl.so.1: " ) + ( dlerror() ? dlerror() : "?" ); return; }
+	g_rccl.reduce = (rccl_reduce_fn)dlsym( h, "ncclReduce" ), g_rccl.allreduce = (rccl_allreduce_fn)dlsym( h, "ncclAllReduce" );
+	g_rccl.errstr = (rccl_errstr_fn)dlsym( h, "ncclGetErrorString" );
+	if (!g_rccl.reduce || !g_rccl.allreduce) g_rccl.how = "librccl has no ncclReduce / ncclAllReduce", g_rccl.reduce = 0, g_rccl.allreduce = 0;
+}
+int rtmi_reduce_accumulator( rtmi_ctx* c, void* comm, int root )
+{
+	if (!c || !comm) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	std::call_once( g_rccl.once, bind_rccl );
+	if (!g_rccl.reduce) return fail( c, RTMI_ERR_HIP, g_rccl.how );
+	{ int r = join_batches( c ); if (r) return r; } // whole samples only, and the collective is ordered after them on the handle's stream
+	const size_t count = (size_t)c->W * c->H * 4;
+	const int ncclFloat = 7, ncclSum = 0; // rccl.h:448, 466
+	const int e = root >= 0 ? g_rccl.reduce( c->accum, c->accum, count, ncclFloat, ncclSum, root, comm, c->stream )
+		: g_rccl.allreduce( c->accum, c->accum, count, ncclFloat, ncclSum, comm, c->stream );
+	if (e != 0) return fail( c, RTMI_ERR_HIP, std::string( root >= 0 ? "ncclReduce: " : "ncclAllReduce: " ) + ( g_rccl.errstr ? g_rccl.errstr( e ) : "error" ) );
 	return RTMI_OK;
 }
 

@@ -30,6 +30,19 @@ void rth_scene_add_torus_knot( void* s, int nu, int nv, float R, float r, float 
 	MakeTorusKnot( nu, nv, R, r, tube, p, q, float3( cx, cy, cz ), v );
 	( (Scene*)s )->AddTriangles( v.data(), v.size() / 9, to_mat( m ) );
 }
+void rth_scene_add_plane( void* s, float nx, float ny, float nz, float d, const rth_material* m ) { ( (Scene*)s )->AddPlane( float3( nx, ny, nz ), d, to_mat( m ) ); }
+void rth_scene_add_quad( void* s, float size, const float* T16, const rth_material* m )
+{
+	mat4 T;
+	memcpy( T.cell, T16, 64 );
+	( (Scene*)s )->AddQuad( size, to_mat( m ), T );
+}
+void rth_scene_add_cube( void* s, const float* pos3, const float* size3, const float* M16, const rth_material* m )
+{
+	mat4 M;
+	memcpy( M.cell, M16, 64 );
+	( (Scene*)s )->AddCube( float3( pos3[0], pos3[1], pos3[2] ), float3( size3[0], size3[1], size3[2] ), to_mat( m ), M );
+}
 int rth_scene_load_obj( void* s, const char* path, const rth_material* m, float ox, float oy, float oz )
 {
 	return ( (Scene*)s )->LoadObject( path, to_mat( m ), float3( ox, oy, oz ) ) ? 0 : -1;
@@ -95,6 +108,25 @@ long long rth_torus_knot( int nu, int nv, float R, float r, float tube, int p, i
 }
 int rth_write_obj( const char* path, const float* v9, long long n ) { return WriteObj( path, v9, (size_t)n ) ? 0 : -1; }
 
+// rtmi::Camera driven by a script of events (host only; the tests compare it with the oracle's restatement of camera.h):
+// ev[2k] = kind, ev[2k+1] = key: 0 KeyDown, 1 KeyUp (through a Renderer that is never initialised: KeyDown/KeyUp only touch the
+// camera), 2 Camera::Update, 3 SetFov( val[k] ), 4 SetAspectRatio( val[k] ); returns the number of updates
+int rth_camera_script( int w, int h, int n, const int* ev, const float* val, float* cam_out, int* moved_out )
+{
+	Renderer r( w, h, 0 );
+	int updates = 0;
+	for (int k = 0; k < n; k++)
+	{
+		const int kind = ev[2 * k], key = ev[2 * k + 1];
+		if (kind == 0) r.KeyDown( key );
+		else if (kind == 1) r.KeyUp( key );
+		else if (kind == 2) { moved_out[updates] = r.camera->Update() ? 1 : 0; memcpy( cam_out + 16 * updates, r.camera->gpuCamProp, 64 ); updates++; }
+		else if (kind == 3) r.camera->SetFov( (int)val[k] );
+		else if (kind == 4) r.camera->SetAspectRatio( val[k] );
+	}
+	return updates;
+}
+
 // ---- Renderer ------------------------------------------------------------------------------------------------
 void* rth_renderer_create( int w, int h, int device ) { return new Renderer( w, h, device ); }
 void rth_renderer_destroy( void* r ) { delete (Renderer*)r; }
@@ -108,6 +140,9 @@ void rth_renderer_set_depth( void* r, int d ) { ( (Renderer*)r )->SetRecusionDep
 void rth_renderer_set_spp_per_tick( void* r, int n ) { ( (Renderer*)r )->samplesPerTick = n > 0 ? n : 1; }
 void rth_renderer_set_postfx( void* r, const rtmi_postfx* fx, int on ) { ( (Renderer*)r )->SetPostFx( *fx, on != 0 ); }
 void rth_renderer_key( void* r, int key, int down ) { if (down) ( (Renderer*)r )->KeyDown( key ); else ( (Renderer*)r )->KeyUp( key ); }
+void rth_renderer_set_fov( void* r, int fov ) { ( (Renderer*)r )->camera->SetFov( fov ); }               // template.cpp:356-357
+void rth_renderer_set_aspect( void* r, float a ) { ( (Renderer*)r )->camera->SetAspectRatio( a ); }     // template.cpp:370-371
+void rth_renderer_camera( void* r, float* cam16 ) { memcpy( cam16, ( (Renderer*)r )->camera->gpuCamProp, 64 ); }
 unsigned rth_renderer_frames( void* r ) { return ( (Renderer*)r )->accumulatedFrames; }
 const uint32_t* rth_renderer_pixels( void* r ) { return ( (Renderer*)r )->screenPixels; }
 const float* rth_renderer_accumulator( void* r ) { Renderer* R = (Renderer*)r; return R->ReadAccumulator() ? &R->accumulator[0].x : 0; }

@@ -27,11 +27,14 @@ void Scene::AddTriangles( const float* v, size_t count, const Material& m, float
 {
 	const size_t base = vt.size();
 	vt.resize( base + count );
+	// no offset: the vertices are taken as they are (x + 0 would turn a -0 coordinate into +0)
+	const bool shift = !( off.x == 0 && off.y == 0 && off.z == 0 );
 #pragma omp parallel for schedule( static )
 	for (long long i = 0; i < (long long)count; i++)
 	{
 		const float* q = v + 9 * i;
-		vt[base + i] = Triangle( 0, float3( q[0], q[1], q[2] ) + off, float3( q[3], q[4], q[5] ) + off, float3( q[6], q[7], q[8] ) + off, m );
+		const float3 a( q[0], q[1], q[2] ), b( q[3], q[4], q[5] ), c( q[6], q[7], q[8] );
+		vt[base + i] = shift ? Triangle( 0, a + off, b + off, c + off, m ) : Triangle( 0, a, b, c, m );
 	}
 }
 

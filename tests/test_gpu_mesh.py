@@ -128,21 +128,17 @@ def test_full_size_image_and_properties(full):
     d.reset()
     d.render(api.PATHTRACING, 0, 4, 1)
     four = d.accumulator()
-    os.environ["RTMI_BATCH"] = "1"
+    d.set_option("batch", 1)
     try:
         d.reset()
         d.render(api.PATHTRACING, 0, 4, 1)
+        assert np.array_equal(bits(d.accumulator()), bits(four))
     finally:
-        del os.environ["RTMI_BATCH"]
-    assert np.array_equal(bits(d.accumulator()), bits(four))
+        d.set_option("batch", 0)
     # late paths (from their 15th vertex on) ride the following batches and add to an exact per-pixel sum;
-    # with RTMI_CARRY=0 every batch finishes all of its paths in a tail of its own.  Same paths, same arithmetic: the images
+    # with option carry = 0 every batch finishes all of its paths in a tail of its own.  Same paths, same arithmetic: the images
     # differ by float summation order only
-    os.environ["RTMI_CARRY"] = "0"
-    try:
-        d0 = api.Device(W, H)
-    finally:
-        del os.environ["RTMI_CARRY"]
+    d0 = api.Device(W, H, carry=0)
     d0.upload(scene.desc)
     d0.set_seeds(seeds)
     d0.set_camera(api.default_camera(W, H, scene.scale))
@@ -151,11 +147,8 @@ def test_full_size_image_and_properties(full):
     d0.close()
     # full buffers: with a carry buffer of 1000 paths and slot lists of 100 nearly every survivor takes the fall-back route
     # (the batch's own k_tail rounds); the image must not change by a bit
-    os.environ["RTMI_CARRY_CAP"], os.environ["RTMI_LEFT_CAP"] = "1000", "100"
-    try:
-        d1 = api.Device(W, H)
-    finally:
-        del os.environ["RTMI_CARRY_CAP"], os.environ["RTMI_LEFT_CAP"]
+    d1 = api.Device(W, H, carry_cap=1000, left_cap=100)
+    assert d1.get_option("carry_cap") == 1000 and d1.get_option("left_cap") == 100
     d1.upload(scene.desc)
     d1.set_seeds(seeds)
     d1.set_camera(api.default_camera(W, H, scene.scale))
@@ -163,12 +156,8 @@ def test_full_size_image_and_properties(full):
     assert np.array_equal(bits(d1.accumulator()), bits(four))
     d1.close()
     # interior nodes: k_trace walks 4-wide nodes with quantised boxes and confirms every hit against the exact box of its
-    # leaf; RTMI_WIDE=0 walks the reference's own boxes (the pairs).  Same hits, same image, bit for bit
-    os.environ["RTMI_WIDE"] = "0"
-    try:
-        d2 = api.Device(W, H)
-    finally:
-        del os.environ["RTMI_WIDE"]
+    # leaf; option wide = 0 walks the reference's own boxes (the pairs).  Same hits, same image, bit for bit
+    d2 = api.Device(W, H, wide=0)
     d2.upload(scene.desc)
     d2.set_seeds(seeds)
     d2.set_camera(api.default_camera(W, H, scene.scale))
@@ -178,19 +167,24 @@ def test_full_size_image_and_properties(full):
     obj1, t1 = d.trace_primary()
     assert np.array_equal(obj1, obj2) and np.array_equal(bits(t1), bits(t2))
     d2.close()
-    # streams: a bounce's shadow walk runs on a side stream beside the next bounce's closest-hit walk; RTMI_OVERLAP=0 runs
+    # streams: a bounce's shadow walk runs on a side stream beside the next bounce's closest-hit walk; option overlap = 0 runs
     # them one after the other on the caller's stream.  Same bits
-    os.environ["RTMI_OVERLAP"] = "0"
-    try:
-        d3 = api.Device(W, H)
-    finally:
-        del os.environ["RTMI_OVERLAP"]
+    d3 = api.Device(W, H, overlap=0)
     d3.upload(scene.desc)
     d3.set_seeds(seeds)
     d3.set_camera(api.default_camera(W, H, scene.scale))
     d3.render(api.PATHTRACING, 0, 4, 1)
     assert np.array_equal(bits(d3.accumulator()), bits(four))
     d3.close()
+    # the end of a render: the last paths are walked by teams of four lanes (k_tail_team); option tail_team = 0 leaves them to
+    # k_tail, one lane per path.  Same visiting order, same arithmetic: same bits.  check_launches synchronises per bounce
+    d4 = api.Device(W, H, tail_team=0, check_launches=1)
+    d4.upload(scene.desc)
+    d4.set_seeds(seeds)
+    d4.set_camera(api.default_camera(W, H, scene.scale))
+    d4.render(api.PATHTRACING, 0, 4, 1)
+    assert np.array_equal(bits(d4.accumulator()), bits(four))
+    d4.close()
     # progressive reads: reading the image between renders (late sums are folded at every read) changes rounding only
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 1)
@@ -328,3 +322,85 @@ def test_renderer_surface(gold_small):
     r.tick()
     want = o.postfx(o.postfx(o.finalize(gold_small["view_normal"], 0).reshape(180, 320), 0, 2.2), 2, 0.8)
     assert (r.pixels() != want).mean() < 1e-3
+
+
+def test_fly_through_resets_and_matches_camera_arithmetic():
+    """SURVEY 8 f4: Renderer::KeyDown -> Tick -> Camera::Update (camera.h:95-140): while the camera moves every Tick ends with
+    accumulatedFrames = 0 and a cleared accumulator (renderer.cpp:622-633); the camera the device renders with is the one the
+    oracle-side restatement of Camera::Update computes, bit for bit; N still frames afterwards equal a fresh render from there."""
+    W, H = 320, 180
+    r = api.Renderer(W, H, 0)
+    assert r.L.rth_scene_make_default(r.scene.h, api.ASSETS.encode(), api.REFERENCE_SAH) == 0
+    r.init()
+    r.set_mode(api.PATHTRACING)
+    orc = Oracle(r.scene.desc)
+    seeds = api.seed_table(W * H)
+    events = []
+
+    def tick_and_check(expect_moved):
+        r.tick()
+        events.append(("update",))
+        cams, moved = orc.camera_script(W, H, events)
+        assert np.array_equal(bits(r.camera()), bits(cams[-1])) and bool(moved[-1]) == expect_moved
+        return cams[-1]
+
+    for _ in range(3):
+        tick_and_check(False)
+    assert r.frames == 3
+    r.key(api.KEY_W, True), events.append(("down", api.KEY_W))
+    r.key(api.KEY_D, True), events.append(("down", api.KEY_D))
+    for _ in range(3):  # moving: each Tick renders one sample from where the camera is, shows it, then discards it
+        cam = tick_and_check(True)
+        assert r.frames == 0 and not r.accumulator().any()
+    assert cam[1] > 0.1 and cam[0] > 0.1  # up and to the right
+    r.key(api.KEY_W, False), events.append(("up", api.KEY_W))
+    r.key(api.KEY_D, False), events.append(("up", api.KEY_D))
+    r.key(api.KEY_LEFT, True), events.append(("down", api.KEY_LEFT))
+    cam = tick_and_check(True)  # rotating about the vertical screen axis by PI/180 per Tick (camera.h:15, 100-115)
+    assert r.frames == 0
+    r.key(api.KEY_LEFT, False), events.append(("up", api.KEY_LEFT))
+    for _ in range(4):
+        cam = tick_and_check(False)
+    assert r.frames == 4
+    acc = r.accumulator()
+    d = api.Device(W, H)
+    d.upload(r.scene.desc)
+    d.set_seeds(seeds)
+    d.set_camera(cam)
+    d.render(api.PATHTRACING, 0, 4, 1)
+    fresh = d.accumulator()
+    assert np.allclose(acc, fresh, rtol=2e-6, atol=1e-6)  # four Ticks fold their late sums four times, one render once
+    ref = orc.sample(W, H, cam, seeds, 0, 4)
+    assert rmse(acc[..., :3], ref[..., :3]) <= 4e-5
+    obj, t = d.trace_primary()
+    o_obj, o_t = orc.primary_hits(W, H, cam)
+    assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+    # SetFov / SetAspectRatio through the handle (template.cpp:356-371)
+    r.set_fov(60), events.append(("fov", 60))
+    r.set_aspect(4.0 / 3.0), events.append(("aspect", 4.0 / 3.0))
+    r.set_mode(api.PATHTRACING)  # restart the accumulation (renderer.h:43-58)
+    cam = tick_and_check(False)
+    assert r.frames == 1
+    d.set_camera(cam)
+    d.reset()
+    d.render(api.PATHTRACING, 0, 1, 1)
+    assert np.array_equal(bits(r.accumulator()), bits(d.accumulator()))
+    assert rmse(d.accumulator()[..., :3], orc.sample(W, H, cam, seeds, 0, 1)[..., :3]) <= 1e-5
+    d.close()
+
+
+def test_full_size_64spp_rows(full):
+    """configs[2] at its own sample count: 64 spp at 1920x1080 (four 16-spp batches, carried paths, late sums), compared
+    with the oracle on a row subset it finishes in seconds; bar RMSE 1e-3 on the normalised image"""
+    scene, d, seeds = full
+    W, H = 1920, 1080
+    d.reset()
+    d.render(api.PATHTRACING, 0, 64, 1)
+    acc = d.accumulator()
+    rows = slice(7, H, 45)
+    ref = Oracle(scene.desc).sample_rows(W, H, api.default_camera(W, H, scene.scale), seeds, 0, 64, 1, 7, 45)
+    e = rmse(acc[rows, :, :3] / 64, ref[rows, :, :3] / 64)
+    assert e <= 1e-5, e
+    px = d.finalize(64)
+    want = Oracle().finalize(ref[rows].reshape(-1, 4), 64).reshape(-1, W)
+    assert (px[rows] != want).mean() < 1e-3  # RGB8 of two images that agree to 1e-5: a few values sit on a truncation boundary

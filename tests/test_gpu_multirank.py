@@ -27,12 +27,19 @@ def _worker(rank, world, port, out_path):
     d.upload(scene.desc)
     d.set_seeds(api.seed_table(W * H))
     d.set_camera(api.default_camera(W, H))
+    # as bench.py does it: a caller-owned device accumulator on an explicit torch stream, rtmi_flush, then the collective on the
+    # device tensor itself -- no host read-back in between that would hide a missing ordering
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    d.set_stream(stream.cuda_stream)
+    d.set_accumulator(acc.data_ptr())
     mine = D.render_split(lambda b, n, st: d.render(api.PATHTRACING, b, n, st), 0, SPP)
     assert mine == SPP // world
-    acc = torch.from_numpy(d.accumulator().copy())  # read-back completes the paths in flight
+    d.flush()
     D.reduce_accumulator(acc, dst=0)
     if rank == 0:
-        np.save(out_path, acc.numpy())
+        np.save(out_path, acc.cpu().numpy())
     dist.barrier()
     d.close()
     dist.destroy_process_group()
@@ -59,3 +66,61 @@ def test_two_gpu_ranks_equal_one(tmp_path):
     ref = Oracle(scene.desc).sample(W, H, api.default_camera(W, H), api.seed_table(W * H), 0, SPP)
     rmse = float(np.sqrt(np.mean((got[..., :3].astype(np.float64) - ref[..., :3]) ** 2))) / SPP
     assert rmse <= 1e-5  # bar 1e-3
+
+
+def _load_rccl():
+    import ctypes as C
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    return None
+
+
+def test_reduce_accumulator_inside_the_boundary():
+    """rtmi_reduce_accumulator: the sum over ranks happens inside the C ABI, on an RCCL communicator the host made.  One
+    process drives every GPU of the box (ncclCommInitAll + group calls): 1 rank here on the one-GPU box (a reduce that must
+    leave the image as it is), 2 ranks where a second GPU is visible (sample split, sum == single render)."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import api
+    lib = _load_rccl()
+    if lib is None:
+        pytest.skip("no librccl.so.1 on this machine")
+    ndev = min(2, torch.cuda.device_count())
+    comms = (C.c_void_p * ndev)()
+    devs = (C.c_int * ndev)(*range(ndev))
+    assert lib.ncclCommInitAll(comms, ndev, devs) == 0
+    scene = api.HostScene.default()
+    seeds = api.seed_table(W * H)
+    ds = []
+    for k in range(ndev):
+        d = api.Device(W, H, k)
+        d.upload(scene.desc)
+        d.set_seeds(seeds)
+        d.render(api.PATHTRACING, k, SPP // ndev, ndev)
+        ds.append(d)
+    for root in (0, -1):  # ncclReduce onto rank 0, then ncclAllReduce of the results (rank 0 holds the sum, the others their own)
+        if root == -1 and ndev > 1:
+            break
+        assert lib.ncclGroupStart() == 0
+        for k, d in enumerate(ds):
+            d.reduce_accumulator(comms[k], root)
+        assert lib.ncclGroupEnd() == 0
+    got = ds[0].accumulator()
+    one = api.Device(W, H, 0)
+    one.upload(scene.desc)
+    one.set_seeds(seeds)
+    one.render(api.PATHTRACING, 0, SPP, 1)
+    want = one.accumulator()
+    if ndev == 1:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    else:
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-6)
+    L = api.device_lib()
+    assert L.rtmi_reduce_accumulator(ds[0].h, None, 0) == -1
+    for d in ds + [one]:
+        d.close()
+    for k in range(ndev):
+        lib.ncclCommDestroy(C.c_void_p(comms[k]))
