@@ -103,10 +103,12 @@ typedef struct rtmi_stats {
 	double   ms_walk;           /* hipEvent time between consecutive shade launches: a bounce's shadow walk and the next bounce's closest-hit walk
 	                               share the chip in it (profiling mode only); ms_extend / ms_connect each span their own launch and overlap */
 	uint64_t n_walk_windows;
-	/* the end-of-render tail kernels, option "tail_profile" only (else 0): lane-summed 100 MHz ticks spent in
-	 * [0] analytic tests of the next ray, [1] closest-hit walk, [2] shading, [3] shadow ray (analytic + walk), and
-	 * [4] path-bounces, [5] node steps, [6] leaf primitive tests, [7] wave-ticks of the whole rounds */
-	uint64_t tail_profile[8];
+	/* the end-of-render tail kernels, option "tail_profile" only (else 0).  Summed over the lanes that lead a path, in 100 MHz
+	 * ticks: [0] analytic tests of the next ray, [1] closest-hit walk, [2] shading, [3] shadow ray (analytic + walk); counts:
+	 * [4] path-bounces, [5] node steps, [6] leaf primitive tests; per wave: [7] ticks and [8] shader cycles of the whole
+	 * rounds (their ratio x 100 MHz = the clock the rounds ran at); k_tail_team only, shader cycles of the closest-hit walks:
+	 * [9] waiting for node records, [10] all of their node steps, [11] the number of those steps */
+	uint64_t tail_profile[12];
 	double   ms_drain;          /* host time spent inside the read-back / flush calls waiting for the last paths (always measured) */
 	uint64_t n_drains;
 } rtmi_stats;

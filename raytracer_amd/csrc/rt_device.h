@@ -400,7 +400,9 @@ __device__ __forceinline__ bool traverse_wide( const DScene& s, f3 O, f3 D, f3 r
 // A path that is alone in its wave (the last few thousand paths of a render) pays for every instruction of its walk at the
 // issue rate of one wave, about 4 cycles each.  Four neighbouring lanes (a DPP quad) therefore share one ray: every
 // lane holds the same ray and the same traversal state, lane j of the team tests child j of a 4-wide node, the four keys
-// are ranked with three quad rotations (1 VALU op each, no LDS), and the team's stack lives in one LDS column.  Nodes are
+// are ranked with three quad rotations (1 VALU op each, no LDS), and the team's stack lives in one LDS column (plain LDS
+// accesses: a lane reads what another lane of its wave wrote earlier in program order, which the in-order LDS queue of a
+// wave guarantees; every such write is a store the compiler sees on the path, so no read is carried over it).  Nodes are
 // visited in exactly the order wide_step visits them and leaf primitives are judged in leaf order, so a team returns what a
 // single lane returns, bit for bit.
 #define RT_QUAD_ROT1( x ) __builtin_amdgcn_update_dpp( 0, (int)( x ), 0x39, 0xF, 0xF, false ) /* lane j reads lane j+1 of its quad */
@@ -408,11 +410,16 @@ __device__ __forceinline__ bool traverse_wide( const DScene& s, f3 O, f3 D, f3 r
 #define RT_QUAD_ROT3( x ) __builtin_amdgcn_update_dpp( 0, (int)( x ), 0x93, 0xF, 0xF, false )
 #define RT_QUAD_BCAST( x, l ) __builtin_amdgcn_update_dpp( 0, (int)( x ), ( l ) * 0x55, 0xF, 0xF, false ) /* every lane reads lane l of its quad */
 #define RT_MISS_KEY 0xFFFFFFFFu
-template <bool ANY>
-__device__ __forceinline__ uint32_t team_wide_step( const DScene& s, uint32_t cur, int j, f3 O, f3 rD, float t, volatile uint32_t* stack, const int stride, int& sp )
+// PROBE (diagnostic builds of k_tail_team only): *probe += shader cycles from the issue of the node's loads to their arrival
+template <bool ANY, bool PROBE = false>
+__device__ __forceinline__ uint32_t team_wide_step( const DScene& s, uint32_t cur, int j, f3 O, f3 rD, float t, uint32_t* stack, const int stride, int& sp, unsigned long long* probe = nullptr )
 {
+	const unsigned long long c0 = PROBE ? __builtin_readcyclecounter() : 0;
 	const float4 q0 = s.wide[4 * cur], q2 = s.wide[4 * cur + 2], q3 = s.wide[4 * cur + 3];
 	const uint32_t ref = ( (const uint32_t*)s.wide )[16 * cur + 4 + j];
+	if (PROBE) { asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" ); *probe += __builtin_readcyclecounter() - c0; }
+	uint32_t ref_pinned = ref;
+	asm volatile( "" : "+v"( ref_pinned ) ); // keep the child reference's load with the node's other loads: one round trip per step, not two
 	const uint32_t ex = __float_as_uint( q0.w );
 	const float sx = __uint_as_float( ( ex & 255u ) << 23 ), sy = __uint_as_float( ( ( ex >> 8 ) & 255u ) << 23 ), sz = __uint_as_float( ( ( ex >> 16 ) & 255u ) << 23 );
 	const uint32_t sh = 8u * (uint32_t)j;
@@ -430,9 +437,9 @@ __device__ __forceinline__ uint32_t team_wide_step( const DScene& s, uint32_t cu
 	const int nhit = (int)hit + (int)( k1 != RT_MISS_KEY ) + (int)( k2 != RT_MISS_KEY ) + (int)( k3 != RT_MISS_KEY );
 	if (nhit == 0) return sp > 0 ? stack[--sp * stride] : RT_DONE; // (the same for the four lanes)
 	// the nearest child next, the others on the stack, farthest deepest (as wide_step pushes them)
-	if (hit && rank >= 1) stack[( sp + nhit - 1 - rank ) * stride] = ref;
+	if (hit && rank >= 1) stack[( sp + nhit - 1 - rank ) * stride] = ref_pinned;
 	sp += nhit - 1;
-	uint32_t next = hit && rank == 0 ? ref : 0u;
+	uint32_t next = hit && rank == 0 ? ref_pinned : 0u;
 	next |= (uint32_t)RT_QUAD_ROT1( next ), next |= (uint32_t)RT_QUAD_ROT2( next ); // after ROT1 lane j holds j | j+1, after ROT2 all four
 	return next;
 }
@@ -445,9 +452,11 @@ __device__ __forceinline__ void prim_candidates( const DScene& s, int pos, f3 O,
 	c.v1 = false, c.v2 = false, c.t1 = 0, c.t2 = 0;
 	const float4 a = s.prims[3 * pos], b = s.prims[3 * pos + 1];
 	c.obj = __float_as_int( b.w );
+	float4 cc4 = s.prims[3 * pos + 2];
+	asm volatile( "" : "+v"( cc4.x ) ); // the third quarter of the record travels with the first two: one round trip per primitive, not two
 	if (__float_as_int( a.w ) == 0)
 	{
-		const float4 cc = s.prims[3 * pos + 2];
+		const float4 cc = cc4;
 		const f3 p1 = mk3( a ), edge1 = mk3( b ), edge2 = mk3( cc );
 		const f3 hh = cross3( D, edge2 );
 		const float det = dot3( edge1, hh );
@@ -474,14 +483,17 @@ __device__ __forceinline__ void prim_candidates( const DScene& s, int pos, f3 O,
 }
 // The walk over the 4-wide nodes by a team (see traverse_wide for the single-lane form it reproduces).  Every lane of the
 // team passes the same ray, hit and stack column; `j` is the lane's number in its team.  Returns true iff ANY and occluded.
-template <bool ANY>
-__device__ __forceinline__ bool team_traverse_wide( const DScene& s, int j, f3 O, f3 D, f3 rD, RayHit& h, volatile uint32_t* stack, const int stride, uint32_t& nSteps, uint32_t& nPrims )
+template <bool ANY, bool PROBE = false>
+__device__ __forceinline__ bool team_traverse_wide( const DScene& s, int j, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride, uint32_t& nSteps, uint32_t& nPrims,
+	unsigned long long* probe = nullptr )
 {
 	uint32_t cur = s.wide_root;
 	int sp = 0;
 	while (true)
 	{
-		while (!( cur & RT_LEAF )) { cur = team_wide_step<ANY>( s, cur, j, O, rD, h.t, stack, stride, sp ); nSteps++; }
+		const unsigned long long c0 = PROBE ? __builtin_readcyclecounter() : 0;
+		while (!( cur & RT_LEAF )) { cur = team_wide_step<ANY, PROBE>( s, cur, j, O, rD, h.t, stack, stride, sp, probe ); nSteps++; }
+		if (PROBE) probe[1] += __builtin_readcyclecounter() - c0; // all node steps of this descent (probe[0]: their fetch waits)
 		if (cur == RT_DONE) break;
 		const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
 		// the exact box of the leaf: a hit found under quantised boxes counts only if this passes the reference's test (traverse_wide)
@@ -521,6 +533,203 @@ __device__ __forceinline__ bool team_traverse_wide( const DScene& s, int j, f3 O
 			}
 		}
 		cur = sp > 0 ? stack[--sp * stride] : RT_DONE;
+	}
+	return false;
+}
+
+// ---- one ray per WAVE (k_tail_wave: the last few thousand paths of a render; the parity hook with hook_kernel = 2) --------
+// A lone ray's walk is a chain of dependent steps, each a fetch (~400 cycles) plus ~100 instructions at the 4-5 cycles a
+// wave alone needs per instruction: about 27 node steps and 5 leaf visits per bounce for a path inside the mirror object,
+// 17 us.  Here the 64 lanes of a wave walk ONE ray breadth-first: every iteration takes up to 16 nodes from a stack in LDS
+// (lane 4q + j tests child j of node q with exactly wide_step's arithmetic) and up to 64 leaf primitives from a queue (one
+// per lane, each with the exact box of its leaf), so the number of dependent steps falls from the number of nodes
+// visited to about the depth of the tree.  The closest hit is the smallest (t, leaf position) over the primitives whose
+// leaf box passes the reference's test -- the rule the other walkers apply primitive by primitive -- found with wave
+// reductions; it does not depend on the order of the visit except in one corner (a hit that lies numerically in front of
+// its own leaf box while a competing hit lies between the two: there the result depends on the order in every walker,
+// the reference's recursion included).
+struct WaveLds
+{
+	enum { NODE_CAP = 512, LEAF_CAP = 256 };
+	uint32_t nref[NODE_CAP]; // node stack: 4-wide node index ...
+	uint32_t nkey[NODE_CAP]; // ... and the entry distance it was pushed with (float bits, rounded down)
+	uint32_t leaf[LEAF_CAP]; // leaf primitive queue: position | offset within its leaf << 25
+};
+__device__ __forceinline__ float wave_min_f32( float v ) // the minimum over the 64 lanes, in every lane
+{
+#define RT_WMIN( ctrl, rm ) v = fminf( v, __int_as_float( __builtin_amdgcn_update_dpp( __float_as_int( v ), __float_as_int( v ), ctrl, rm, 0xF, false ) ) );
+	RT_WMIN( 0xB1, 0xF ) RT_WMIN( 0x4E, 0xF ) RT_WMIN( 0x124, 0xF ) RT_WMIN( 0x128, 0xF ) RT_WMIN( 0x142, 0xA ) RT_WMIN( 0x143, 0xC )
+#undef RT_WMIN
+	return __int_as_float( __builtin_amdgcn_readlane( __float_as_int( v ), 63 ) );
+}
+__device__ __forceinline__ uint32_t wave_min_u32( uint32_t v )
+{
+#define RT_WMIN( ctrl, rm ) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp( (int)v, (int)v, ctrl, rm, 0xF, false ); v = o < v ? o : v; }
+	RT_WMIN( 0xB1, 0xF ) RT_WMIN( 0x4E, 0xF ) RT_WMIN( 0x124, 0xF ) RT_WMIN( 0x128, 0xF ) RT_WMIN( 0x142, 0xA ) RT_WMIN( 0x143, 0xC )
+#undef RT_WMIN
+	return (uint32_t)__builtin_amdgcn_readlane( (int)v, 63 );
+}
+__device__ __forceinline__ uint32_t lane_rank( unsigned long long m ) { return __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0 ) ); }
+
+// The analytic part of Scene::FindNearest (isect_analytic: quads[0], cubes[0], the planes in order, each accepted when
+// closer than what came before) with one candidate per lane: lane 0 the quad, lane 1 the cube, lanes 2.. the planes.
+// "Closer than what came before" in that order is the smallest distance, the earliest candidate among equals.
+__device__ __forceinline__ void wave_analytic( const DScene& s, int lane, f3 O, f3 D, float t0, RayHit& h )
+{
+	float best = INFINITY;
+	int bestObj = -1;
+	for (int base = 0; base < 2 + s.n_planes; base += 64) // (one round unless a scene has more than 62 planes)
+	{
+		RayHit c; c.t = t0, c.obj = -1, c.pos = -1;
+		const int k = base + lane;
+		if (k == 0) { if (s.n_quads > 0) isect_quad( s, 0, O, D, c ); }
+		else if (k == 1) { if (s.n_cubes > 0) isect_cube( s, 0, O, D, c ); }
+		else if (k - 2 < s.n_planes) isect_plane( s, k - 2, O, D, c );
+		const float tc = c.obj != -1 ? c.t : INFINITY;
+		const float tm = wave_min_f32( tc );
+		if (tm < best) // (the same in every lane) strictly closer than the earlier rounds' best
+		{
+			const unsigned long long m = __ballot( tc == tm );
+			best = tm, bestObj = __builtin_amdgcn_readlane( c.obj, __ffsll( (long long)m ) - 1 );
+		}
+	}
+	h.t = bestObj != -1 ? best : t0, h.obj = bestObj, h.pos = -1;
+}
+// Scene::IsOccluded before the BVH: any of them closer than the ray's end occludes (begin_any without the order)
+__device__ __forceinline__ bool wave_analytic_any( const DScene& s, int lane, f3 O, f3 D, float tmaxRay )
+{
+	bool occ = false;
+	for (int base = 0; base < 2 + s.n_planes && !occ; base += 64)
+	{
+		RayHit c; c.t = tmaxRay, c.obj = -1, c.pos = -1;
+		const int k = base + lane;
+		if (k == 0) { if (s.n_quads > 0) isect_quad( s, 0, O, D, c ); }
+		else if (k == 1) { if (s.n_cubes > 0) isect_cube( s, 0, O, D, c ); }
+		else if (k - 2 < s.n_planes) isect_plane( s, k - 2, O, D, c );
+		occ = __ballot( c.obj != -1 ) != 0;
+	}
+	return occ;
+}
+
+// The walk.  Every lane passes the same ray and hit; returns true iff ANY and occluded.  `overflow`: the node stack or the
+// leaf queue would not hold what this ray pushes -- the caller walks the ray another way (result untouched: h restored).
+template <bool ANY>
+__device__ __forceinline__ bool wave_traverse_wide( const DScene& s, int lane, f3 O, f3 D, f3 rD, RayHit& h, WaveLds& L, bool& overflow, uint32_t& nIter )
+{
+	const RayHit h0 = h;
+	overflow = false;
+	const int j = lane & 3, q = lane >> 2;
+	if (lane == 0) L.nref[0] = s.wide_root, L.nkey[0] = 0u;
+	int nN = 1, nL = 0; // entries on the node stack / in the leaf queue (the same in every lane)
+	while (nN > 0 || nL > 0)
+	{
+		nIter++;
+		// ---- issue this iteration's fetches together: up to 16 nodes from the top of the stack, up to 64 leaf primitives
+		const int takeN = nN < 16 ? nN : 16, takeL = nL < 64 ? nL : 64;
+		uint32_t node = 0, nodeKey = 0;
+		float4 q0 = make_float4( 0, 0, 0, 0 ), q2 = q0, q3 = q0;
+		uint32_t ref = RT_LEAF;
+		const bool haveNode = q < takeN;
+		if (haveNode)
+		{
+			node = L.nref[nN - 1 - q], nodeKey = L.nkey[nN - 1 - q];
+			q0 = s.wide[4 * node], q2 = s.wide[4 * node + 2], q3 = s.wide[4 * node + 3];
+			ref = ( (const uint32_t*)s.wide )[16 * node + 4 + j];
+		}
+		const bool haveLeaf = lane < takeL;
+		PrimCand c;
+		c.v1 = false, c.v2 = false, c.t1 = 0, c.t2 = 0, c.obj = -1;
+		int pos = 0;
+		float tmn = 0, tmx = -1;
+		if (haveLeaf)
+		{
+			const uint32_t e = L.leaf[nL - 1 - lane];
+			pos = (int)( e & RT_LEAF_FIRST_MASK );
+			const int first = pos - (int)( e >> RT_LEAF_FIRST_BITS );
+			const float4 b0 = s.leafbox[2 * first], b1 = s.leafbox[2 * first + 1];
+			prim_candidates( s, pos, O, D, c );
+			slab<false>( b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, O, rD, tmn, tmx );
+		}
+		nN -= takeN, nL -= takeL;
+		// ---- leaf primitives first: a closer hit prunes the children tested below
+		if (takeL > 0) // (the same in every lane)
+		{
+			const bool boxAlive = tmx >= tmn && tmx > 0;
+			if (ANY)
+			{
+				const bool occ = haveLeaf && boxAlive && tmn < h.t && ( ( c.v1 && c.t1 < h.t ) || ( c.v2 && c.t2 < h.t ) );
+				if (__ballot( occ ) != 0) return true;
+			}
+			else
+			{
+				// this lane's candidate as isect_prim would judge it against the hit so far, confirmed by its leaf's exact box
+				const bool a1 = c.v1 && ( c.t1 < h.t || ( c.t1 == h.t && pos < h.pos ) );
+				const bool a2 = !a1 && c.v2 && ( c.t2 < h.t || ( c.t2 == h.t && pos < h.pos ) );
+				const bool ok = haveLeaf && ( a1 || a2 ) && boxAlive && tmn <= h.t;
+				const float tc = ok ? ( a1 ? c.t1 : c.t2 ) : INFINITY;
+				const float tm = wave_min_f32( tc );
+				if (tm < INFINITY) // the smallest (t, position) of the batch
+				{
+					const uint32_t pm = wave_min_u32( tc == tm ? (uint32_t)pos : 0xFFFFFFFFu );
+					const unsigned long long m = __ballot( tc == tm && (uint32_t)pos == pm );
+					h.t = tm, h.pos = (int)pm, h.obj = __builtin_amdgcn_readlane( c.obj, __ffsll( (long long)m ) - 1 );
+				}
+			}
+		}
+		// ---- children of the nodes (wide_step's arithmetic, child j of node q in lane 4q + j)
+		if (takeN > 0)
+		{
+			uint32_t key = RT_MISS_KEY;
+			// a node pushed before the hit got closer than its entry distance needs no test (its key was rounded down: never wrong)
+			if (haveNode && ( nodeKey & ~3u ) <= __float_as_uint( h.t ))
+			{
+				const uint32_t ex = __float_as_uint( q0.w );
+				const float sx = __uint_as_float( ( ex & 255u ) << 23 ), sy = __uint_as_float( ( ( ex >> 8 ) & 255u ) << 23 ), sz = __uint_as_float( ( ( ex >> 16 ) & 255u ) << 23 );
+				const uint32_t sh = 8u * (uint32_t)j;
+				const uint32_t lox = ( __float_as_uint( q2.x ) >> sh ) & 255u, loy = ( __float_as_uint( q2.y ) >> sh ) & 255u, loz = ( __float_as_uint( q2.z ) >> sh ) & 255u;
+				const uint32_t hix = ( __float_as_uint( q2.w ) >> sh ) & 255u, hiy = ( __float_as_uint( q3.x ) >> sh ) & 255u, hiz = ( __float_as_uint( q3.y ) >> sh ) & 255u;
+				const float tnx = ( __builtin_fmaf( (float)( rD.x < 0 ? hix : lox ), sx, q0.x ) - O.x ) * rD.x, tfx = ( __builtin_fmaf( (float)( rD.x < 0 ? lox : hix ), sx, q0.x ) - O.x ) * rD.x;
+				const float tny = ( __builtin_fmaf( (float)( rD.y < 0 ? hiy : loy ), sy, q0.y ) - O.y ) * rD.y, tfy = ( __builtin_fmaf( (float)( rD.y < 0 ? loy : hiy ), sy, q0.y ) - O.y ) * rD.y;
+				const float tnz = ( __builtin_fmaf( (float)( rD.z < 0 ? hiz : loz ), sz, q0.z ) - O.z ) * rD.z, tfz = ( __builtin_fmaf( (float)( rD.z < 0 ? loz : hiz ), sz, q0.z ) - O.z ) * rD.z;
+				const float tmin = fmaxf( fmaxf( fmaxf( tnx, tny ), tnz ), 0.0f ), tmax = fminf( fminf( fminf( tfx, tfy ), tfz ), h.t );
+				if (tmin <= tmax) key = ( __float_as_uint( tmin ) & ~3u ) | (uint32_t)j;
+			}
+			const bool hit = key != RT_MISS_KEY;
+			const uint32_t k1 = (uint32_t)RT_QUAD_ROT1( key ), k2 = (uint32_t)RT_QUAD_ROT2( key ), k3 = (uint32_t)RT_QUAD_ROT3( key );
+			const int rank = (int)( k1 < key ) + (int)( k2 < key ) + (int)( k3 < key ); // among the children of its own node
+			const bool toLeaf = hit && ( ref & RT_LEAF ) != 0, toNode = hit && !toLeaf;
+			// interior children: onto the stack, every node's farthest first and nearest last, so that the next iteration
+			// takes the nearest child of each of these nodes from the top
+			const unsigned long long mAll = __ballot( toNode );
+			if (nN + __popcll( mAll ) > WaveLds::NODE_CAP) { overflow = true; h = h0; return false; }
+			if (nN + __popcll( mAll ) <= 16) // the next iteration takes them all: their order on the stack does not matter
+			{
+				if (toNode) { const int at = nN + (int)lane_rank( mAll ); L.nref[at] = ref, L.nkey[at] = key; }
+				nN += __popcll( mAll );
+			}
+			else
+			{
+#pragma unroll
+				for (int r = 3; r >= 0; r--)
+				{
+					const bool mine = toNode && rank == r;
+					const unsigned long long m = __ballot( mine );
+					if (mine) { const int at = nN + (int)lane_rank( m ); L.nref[at] = ref, L.nkey[at] = key; }
+					nN += __popcll( m );
+				}
+			}
+			// leaf children: every primitive of the leaf becomes one entry of the queue
+			const int cnt = toLeaf ? (int)( ( ref >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1 : 0;
+			const int first = (int)( ref & RT_LEAF_FIRST_MASK );
+			for (int r = 0; __ballot( r < cnt ) != 0; r++)
+			{
+				const bool mine = r < cnt;
+				const unsigned long long m = __ballot( mine );
+				if (nL + __popcll( m ) > WaveLds::LEAF_CAP) { overflow = true; h = h0; return false; }
+				if (mine) L.leaf[nL + (int)lane_rank( m )] = (uint32_t)( first + r ) | ( (uint32_t)r << RT_LEAF_FIRST_BITS );
+				nL += __popcll( m );
+			}
+		}
 	}
 	return false;
 }

@@ -69,10 +69,11 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 	uint32_t pool_connect; // same for k_trace<any>
 	uint32_t pending;      // paths + carried shadow rays that the next bounce starts with (host loop termination)
 	uint32_t pool_tail;    // next unclaimed entry of the running k_tail round
-	uint32_t pad[2];
+	uint32_t tail_mode;    // which kernel the running tail round belongs to (k_tail_decide): 0 k_tail, 1 k_tail_team, 2 k_tail_wave
+	uint32_t pad[1];
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
 	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
-	unsigned long long tail_prof[8]; // option tail_profile: see rtmi_stats.tail_profile
+	unsigned long long tail_prof[12]; // option tail_profile: see rtmi_stats.tail_profile
 };
 
 #define FLAG_SPECULAR 1u
@@ -710,9 +711,9 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	// the chip is this kernel's, so a round (round 0 excepted) spreads its paths over all the waves of the grid, as few to a
 	// wave as that allows: a path's bounce waits for the walks of the others in its wave
 	const bool hurry = dense_above != 0 && *(const volatile uint32_t*)draining != 0;
-	if (hurry && n <= team_below) return; // this round is k_tail_team's (launched right after this kernel with the same arguments)
+	if (team_below && ctr->tail_mode != 0) return; // this round is k_tail_team's or k_tail_wave's (k_tail_decide; launched right after this kernel)
 	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0;
+	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
 	int per_wave;
 	if (hurry)
 	{
@@ -813,11 +814,21 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	} // next per_wave paths
 	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
-	if (PROF)
+	if (PROF && hurry && n <= 16384u) // the profile covers the regime k_tail_team is for: draining rounds with few paths left
 	{
 		for (int k = 0; k < 5; k++) wave_add64( prof[k], &ctr->tail_prof[k] );
-		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 );
+		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 ), atomicAdd( &ctr->tail_prof[8], __builtin_readcyclecounter() - prof_c0 );
 	}
+}
+
+// Which kernel runs a tail round is decided ONCE per round, here, from the live path count and from whether the host is
+// waiting (`draining`, pinned host memory that the host may flip at any time -- between two launches of one round too, which
+// is why the three kernels do not each look for themselves: a round must have exactly one taker).
+__global__ void k_tail_decide( DevCounters* ctr, const uint32_t* __restrict__ n_in, const uint32_t* draining, uint32_t team_below, uint32_t wave_below )
+{
+	const uint32_t n = *n_in;
+	const bool waiting = *(const volatile uint32_t*)draining != 0;
+	ctr->tail_mode = waiting && n <= wave_below ? 2u : waiting && n <= team_below ? 1u : 0u;
 }
 
 // ---- the end of a render: teams of four lanes per path -------------------------------------------------------------------
@@ -830,11 +841,11 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 // arithmetic, same results as k_tail, which stays in charge of every round that is not a draining round with few paths.
 template <bool PROF>
 __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t team_below, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t team_below, uint32_t wave_below, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t n = *n_in;
-	if (!( *(const volatile uint32_t*)draining != 0 && n <= team_below )) return; // k_tail's round
+	if (ctr->tail_mode != 1) return; // k_tail's or k_tail_wave's round (k_tail_decide)
 	// teams per wave: as few as the grid allows (a team's bounce waits for the divergence of the other teams of its wave)
 	const uint32_t waves_per_block = blockDim.x >> 6, waves = gridDim.x * waves_per_block;
 	const uint32_t need = ( n + waves - 1 ) / waves;
@@ -845,11 +856,11 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 	const int j = (int)( lane & 3u );
 	const uint32_t tm = lane >> 2;
 	const int stride = (int)( waves_per_block * 16u );
-	volatile uint32_t* stack = lds_stack + wave_in_block * 16u + tm; // one column per team
+	uint32_t* stack = lds_stack + wave_in_block * 16u + tm; // one column per team
 	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
-	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0;
-	uint32_t nSteps = 0, nPrims = 0;
+	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, probe[2] = { 0, 0 };
+	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
+	uint32_t nSteps = 0, nPrims = 0, nStepsAny = 0, nPrimsAny = 0;
 	TravCount tc; tc.pairs = 0, tc.prims = 0;
 	for (;;)
 	{
@@ -881,9 +892,9 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 					// rays that the 4-wide nodes cannot take walk the pairs, the four lanes in step (same values to the same column)
-					if (inexact) traverse<false, true, false>( s, O, D, rD, h, const_cast<uint32_t*>( stack ), stride, tc );
-					else if (s.wide) team_traverse_wide<false>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims );
-					else traverse<false, false, false>( s, O, D, rD, h, const_cast<uint32_t*>( stack ), stride, tc );
+					if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, stride, tc );
+					else if (s.wide) team_traverse_wide<false, PROF>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims, probe );
+					else traverse<false, false, false>( s, O, D, rD, h, stack, stride, tc );
 				}
 				if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x; }
 				Vertex v;
@@ -903,9 +914,9 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, const_cast<uint32_t*>( stack ), stride, tc )
-							: s.wide ? team_traverse_wide<true>( s, j, v.shO, v.shD, rD, sh, stack, stride, nSteps, nPrims )
-							: traverse<true, false, false>( s, v.shO, v.shD, rD, sh, const_cast<uint32_t*>( stack ), stride, tc );
+						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, stride, tc )
+							: s.wide ? team_traverse_wide<true>( s, j, v.shO, v.shD, rD, sh, stack, stride, nStepsAny, nPrimsAny )
+							: traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, stride, tc );
 						if (!occ && j == 0) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
 				}
@@ -936,9 +947,154 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
 	if (PROF)
 	{
-		prof[5] = nSteps, prof[6] = nPrims;
+		prof[5] = nSteps + nStepsAny, prof[6] = nPrims + nPrimsAny;
+		wave_add64( j == 0 ? (unsigned long long)nSteps : 0ull, &ctr->tail_prof[11] );
 		for (int k = 0; k < 7; k++) wave_add64( j == 0 ? prof[k] : 0ull, &ctr->tail_prof[k] );
-		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 );
+		wave_add64( j == 0 ? probe[0] : 0ull, &ctr->tail_prof[9] ), wave_add64( j == 0 ? probe[1] : 0ull, &ctr->tail_prof[10] );
+		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 ), atomicAdd( &ctr->tail_prof[8], __builtin_readcyclecounter() - prof_c0 );
+	}
+}
+
+// ---- the very end of a render: one path per wave ---------------------------------------------------------------------------
+// Below a few thousand live paths even a team leaves 60 lanes of its wave idle while its path's walk is a chain of ~30
+// dependent steps.  Here the whole wave walks the one path breadth-first (rt_device.h: wave_traverse_wide), the analytic
+// primitives are tested one per lane, and shading runs replicated as in k_tail_team; lane 0 writes.
+__device__ __forceinline__ void wave_find_nearest( const DScene& s, int lane, f3 O, f3 D, float t0, RayHit& h, WaveLds& L, bool& walked, uint32_t& nIter )
+{
+	wave_analytic( s, lane, O, D, t0, h );
+	walked = false;
+	if (s.n_bvh_prims == 0) return;
+	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	if (( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) == RT_DONE) return;
+	walked = true;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	// rays the 4-wide nodes cannot take, and rays whose frontier outgrows the LDS, walk as in k_tail: the 64 lanes in step,
+	// one stack column (the same values to the same addresses)
+	if (inexact) { traverse<false, true, false>( s, O, D, rD, h, L.nref, 1, tc ); return; }
+	if (!s.wide) { traverse<false, false, false>( s, O, D, rD, h, L.nref, 1, tc ); return; }
+	bool overflow;
+	wave_traverse_wide<false>( s, lane, O, D, rD, h, L, overflow, nIter );
+	if (overflow) traverse_wide<false>( s, O, D, rD, h, L.nref, 1 );
+}
+__device__ __forceinline__ bool wave_is_occluded( const DScene& s, int lane, f3 O, f3 D, float tmaxRay, WaveLds& L, bool& walked, uint32_t& nIter )
+{
+	walked = false;
+	if (wave_analytic_any( s, lane, O, D, tmaxRay )) return true;
+	if (s.n_bvh_prims == 0) return false;
+	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
+	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	if (( inexact ? bvh_enter<true>( s, O, rD, tmaxRay ) : bvh_enter<false>( s, O, rD, tmaxRay ) ) == RT_DONE) return false;
+	walked = true;
+	RayHit sh; sh.t = tmaxRay, sh.obj = -1, sh.pos = -1;
+	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	if (inexact) return traverse<true, true, false>( s, O, D, rD, sh, L.nref, 1, tc );
+	if (!s.wide) return traverse<true, false, false>( s, O, D, rD, sh, L.nref, 1, tc );
+	bool overflow;
+	const bool occ = wave_traverse_wide<true>( s, lane, O, D, rD, sh, L, overflow, nIter );
+	return overflow ? traverse_wide<true>( s, O, D, rD, sh, L.nref, 1 ) : occ;
+}
+
+#define WAVE_WG 8 // waves per k_tail_wave workgroup: an empty round costs the dispatch of its workgroups, so few large ones
+template <bool PROF>
+__global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
+	uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t wave_below, DevCounters* ctr )
+{
+	__shared__ WaveLds lds[WAVE_WG];
+	const uint32_t n = *n_in;
+	if (ctr->tail_mode != 2) return; // another tail kernel's round (k_tail_decide)
+	const int lane = (int)( threadIdx.x & 63u );
+	WaveLds& L = lds[threadIdx.x >> 6];
+	if (( blockIdx.x * (uint32_t)WAVE_WG + ( threadIdx.x >> 6 ) ) >= n) return; // surplus waves leave at once
+	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
+	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
+	uint32_t nIter = 0, nIterAny = 0;
+	for (;;)
+	{
+		uint32_t i = 0;
+		if (lane == 0) i = atomicAdd( &ctr->pool_tail, 1u );
+		i = (uint32_t)__builtin_amdgcn_readfirstlane( (int)i );
+		if (i >= n) break;
+		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
+		const uint32_t meta = in.meta[i];
+		uint32_t slot = meta & META_SLOT_MASK, flags = meta >> 30, rng = __float_as_uint( ts.w ), age = ( meta >> META_AGE_SHIFT ) & META_AGE_LATE;
+		f3 O = mk3( ot ), D = mk3( dh ), T = mk3( ts );
+		bool alive = true;
+		for (int nb = 0; nb < max_bounces; nb++)
+		{
+			RayHit h;
+			bool walked;
+			unsigned long long tp = PROF ? wall_clock64() : 0;
+			wave_find_nearest( s, lane, O, D, 1e34f, h, L, walked, nIter );
+			if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x, prof[4]++; }
+			nExt++, nExtWalk += walked ? 1 : 0;
+			Vertex v;
+			const bool late = age == META_AGE_LATE;
+			shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v, lane == 0 );
+			age = age < META_AGE_LATE ? age + 1 : age;
+			if (PROF) { const unsigned long long x = wall_clock64(); prof[2] += x - tp, tp = x; }
+			if (v.shadow_any)
+			{
+				nSh++;
+				const bool occ = wave_is_occluded( s, lane, v.shO, v.shD, v.shT, L, walked, nIterAny );
+				nShWalk += walked ? 1 : 0;
+				if (!occ && lane == 0)
+				{
+					if (walked) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
+					else add_chain( sinks, slot, late, v.contrib );
+				}
+			}
+			if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
+			if (!v.push_next) { alive = false; break; }
+			O = v.newO, D = v.newD;
+		}
+		if (alive && lane == 0) // survivor of this round
+		{
+			const uint32_t k = atomicAdd( n_out, 1u );
+			out.o_t[k] = make_float4( O.x, O.y, O.z, 1e34f );
+			out.d_h[k] = make_float4( D.x, D.y, D.z, __int_as_float( -1 ) );
+			out.T_s[k] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
+			out.meta[k] = slot | ( age << META_AGE_SHIFT ) | ( flags << 30 );
+		}
+	}
+	if (lane == 0)
+	{
+		atomicAdd( &ctr->extend_rays, nExt ), atomicAdd( &ctr->shadow_rays, nSh ), atomicAdd( &ctr->extend_walkers, nExtWalk ), atomicAdd( &ctr->shadow_walkers, nShWalk );
+		if (PROF)
+		{
+			prof[5] = nIter + nIterAny;
+			for (int k = 0; k < 7; k++) if (prof[k]) atomicAdd( &ctr->tail_prof[k], prof[k] );
+			atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 ), atomicAdd( &ctr->tail_prof[8], __builtin_readcyclecounter() - prof_c0 );
+			atomicAdd( &ctr->tail_prof[11], (unsigned long long)nIter );
+		}
+	}
+}
+
+// the parity hook through the same code (option hook_kernel = 2): wave w walks caller rays w, w + waves, ...
+__global__ __launch_bounds__( 256 ) void k_rays_wave( DScene s, int n, const float* __restrict__ O3, const float* __restrict__ D3, const float* __restrict__ tmax,
+	int any_hit, int* __restrict__ obj_out, float* __restrict__ t_out )
+{
+	__shared__ WaveLds lds[4];
+	const int lane = (int)( threadIdx.x & 63u );
+	WaveLds& L = lds[threadIdx.x >> 6];
+	const int waves = (int)gridDim.x * 4;
+	uint32_t nIter = 0;
+	for (int i = (int)blockIdx.x * 4 + (int)( threadIdx.x >> 6 ); i < n; i += waves)
+	{
+		const f3 O = mk3( O3[3 * i], O3[3 * i + 1], O3[3 * i + 2] ), D = mk3( D3[3 * i], D3[3 * i + 1], D3[3 * i + 2] );
+		bool walked;
+		if (any_hit)
+		{
+			const bool occ = wave_is_occluded( s, lane, O, D, tmax[i], L, walked, nIter );
+			if (lane == 0) obj_out[i] = occ ? 1 : 0, t_out[i] = tmax[i];
+		}
+		else
+		{
+			RayHit h;
+			wave_find_nearest( s, lane, O, D, tmax[i], h, L, walked, nIter );
+			if (lane == 0) obj_out[i] = h.obj, t_out[i] = h.t;
+		}
 	}
 }
 
@@ -1441,10 +1597,14 @@ struct rtmi_ctx
 	bool tail_paths_set = false;
 	bool check_launches = false; // option check_launches: synchronise and check after every bounce (localises a fault; slow)
 	int hook_kernel = 0;        // option hook_kernel: rtmi_trace_rays runs 0 = k_trace_rays (one ray per lane over the reference's pairs),
-	                            // 1 = the render path's own queues and persistent walk (k_trace: 4-wide nodes where built)
-	bool tail_team = true;      // option tail_team: the end-of-render rounds run k_tail_team (four lanes per path) once few paths are left
+	                            // 1 = the render path's own queues and persistent walk (k_trace: 4-wide nodes where built),
+	                            // 2 = the end-of-render walker, one ray per wave (k_rays_wave = k_tail_wave's device code)
+	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
 	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
-	uint32_t team_below = 1u << 14; // option team_below: live paths at or below which a draining round uses k_tail_team
+	uint32_t team_below = 1u << 17; // option team_below.  Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds):
+	                            // k_tail alone 372 ms, teams below 16 k 349, below 64 k 296, below 128 k 281, below 256 k 282
+	bool tail_wave = true;      // option tail_wave: ... and k_tail_wave (one path per wave) at or below wave_below live paths
+	uint32_t wave_below = 1u << 12; // = the resident waves k_tail_wave gets: a wave per path.  Above it a round is a matter of throughput (k_tail)
 	// device scratch of the parity hooks and rtmi_postprocess, grown on demand and kept (no allocation per call)
 	void* hook_buf = 0; size_t hook_cap = 0;
 	uint32_t gamma_host[256]; float gamma_cached = 0; // host image of gamma_lut (lives as long as the copy needs it)
@@ -1568,33 +1728,57 @@ static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E,
 // k_tail rounds of 32, 64, 128, ... bounces over the state set st[cur] (length ctr->n_state[cur], at most `upper`), enqueued
 // blind on `ts` (a round over an empty queue returns at once); survivors are compacted between rounds, the last round has no
 // limit.  An even number of rounds: the set that was current at the start is current, and empty, at the end.
-static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int cur, DevCounters* ctr, const Sinks& sinks, uint32_t upper, int first_round = 0, int last_round = 11 )
+// `drain`: these are the rounds the caller waits for (join_batches): the rounds with few live paths go to k_tail_wave /
+// k_tail_team.  Which kernel a round belongs to is decided on the device (live count, draining flag): all are launched and the
+// ones whose round it is not return at once -- every kernel pulls its paths from a pool, so any grid size is correct and an
+// unexpectedly large round is only slower.
+static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int cur, DevCounters* ctr, const Sinks& sinks, uint32_t upper, int first_round = 0, int last_round = 11, bool drain = false )
 {
 	const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves );
 	for (int round = first_round, len = 32 << first_round; round <= last_round; round++, len *= 2)
 	{
 		const int limit = round == 11 ? 0x7FFFFFFF : len;
+		const bool coop = drain && c->ds.wide && round > 0;
+		const uint32_t wave_below = coop && c->tail_wave ? c->wave_below : 0u;
+		const uint32_t team_below = std::max( wave_below, coop && c->tail_team ? c->team_below : 0u ); // k_tail yields at or below this
 		// waves: enough for the round's upper bound at the density the kernel will choose at most (it reads the live count)
 		const uint32_t waves = std::max( 1u, std::min( max_waves, ( upper + c->tail_lanes - 1 ) / c->tail_lanes ) );
 		const uint32_t wpb = std::max( 1u, std::min( (uint32_t)c->tail_block, 65536u / ( (uint32_t)c->walk_depth * 256u ) ) ), blocks = ( waves + wpb - 1 ) / wpb; // <= 64 KiB of LDS per block
 		const uint32_t lds_words = (uint32_t)c->walk_depth * 64u * wpb;
 		// a draining round with few paths left belongs to k_tail_team (the device knows the live count and whether the host waits:
 		// both kernels are launched, the one whose round it is not returns at once)
-		const uint32_t team_below = c->tail_team && c->ds.wide && round > 0 ? c->team_below : 0u;
+		if (team_below) hipLaunchKernelGGL( k_tail_decide, dim3( 1 ), dim3( 1 ), 0, ts, ctr, &ctr->n_state[cur], c->draining_dev, team_below, wave_below );
 		if (c->tail_profile)
 			hipLaunchKernelGGL( k_tail<true>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
 				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
 		else
 			hipLaunchKernelGGL( k_tail<false>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
 				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
-		if (team_below)
+		if (team_below > wave_below)
 		{
 			const uint32_t twaves = std::max( 1u, std::min( max_waves, std::min( upper, team_below ) ) ), tblocks = ( twaves + 3 ) / 4;
 			const size_t tlds = (size_t)c->walk_depth * 64u * sizeof( uint32_t ); // 4 waves x 16 teams, one column each
 			if (c->tail_profile)
-				hipLaunchKernelGGL( k_tail_team<true>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, ctr );
+				hipLaunchKernelGGL( k_tail_team<true>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, wave_below, ctr );
 			else
-				hipLaunchKernelGGL( k_tail_team<false>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, ctr );
+				hipLaunchKernelGGL( k_tail_team<false>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, wave_below, ctr );
+		}
+		if (wave_below)
+		{
+			// one wave per path, as many waves as the round can have paths (a wave that finds the pool empty leaves at once)
+			// (the rounds of 4096 bounces and more are for a handful of paths: fewer waves, cheaper to dispatch when they find nothing)
+			const uint32_t wwaves = std::max( 1u, std::min( round >= 7 ? 1024u : max_waves, std::min( upper, wave_below ) ) ), wblocks = ( wwaves + WAVE_WG - 1 ) / WAVE_WG;
+			if (c->tail_profile)
+				hipLaunchKernelGGL( k_tail_wave<true>, dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, wave_below, ctr );
+			else
+				hipLaunchKernelGGL( k_tail_wave<false>, dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, wave_below, ctr );
+		}
+		if (c->log_bounces && drain) // diagnostics: the survivors of every draining round (synchronises)
+		{
+			uint32_t left = 0;
+			(void)hipStreamSynchronize( ts );
+			(void)hipMemcpy( &left, &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost );
+			fprintf( stderr, "rtmi: drain round %d (%d bounces): %u paths survive\n", round, limit, left );
 		}
 		hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 		cur ^= 1;
@@ -1710,7 +1894,8 @@ static const OptDesc g_opts[] = {
 	{ "tail_block", 1, 16 }, { "tail_dense", 0, 1ll << 32 }, { "tail_mid", 0, 1ll << 32 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
-	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 1 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
+	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -1744,6 +1929,8 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "tail_team" )) c->tail_team = v != 0;
 	else if (is( "tail_profile" )) c->tail_profile = v != 0;
 	else if (is( "team_below" )) c->team_below = (uint32_t)v;
+	else if (is( "tail_wave" )) c->tail_wave = v != 0;
+	else if (is( "wave_below" )) c->wave_below = (uint32_t)v;
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
 	{
@@ -1775,6 +1962,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below;
 	found = false;
 	return 0;
 }
@@ -2477,7 +2665,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			cur ^= 1;
 			launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), 4096, 1, 11 ); // normally nothing: a small persistent grid
 		}
-		else launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper );
+		else launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 11, last );
 		c->stats.bounce_launches++;
 	}
 	if (c->last_acc) HIPCHK( hipStreamWaitEvent( ts, c->last_acc, 0 ) ); // accumulate in batch order
@@ -2507,7 +2695,7 @@ static int fetch_counters( rtmi_ctx* c )
 		c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
 		c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
 		c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
-		for (int i = 0; i < 8; i++) c->stats.tail_profile[i] += h.tail_prof[i];
+		for (int i = 0; i < 12; i++) c->stats.tail_profile[i] += h.tail_prof[i];
 		// the ray counters only: the queue lengths of the carry buffer stay
 		HIPCHK( hipMemset( (char*)src + offsetof( DevCounters, extend_rays ), 0, sizeof( DevCounters ) - offsetof( DevCounters, extend_rays ) ) );
 	}
@@ -2590,6 +2778,13 @@ static int launch_trace_rays( rtmi_ctx* c, int n, const float* dO, const float* 
 	if (c->hook_kernel == 0)
 	{
 		hipLaunchKernelGGL( k_trace_rays, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+		HIPCHK( hipGetLastError() );
+		return RTMI_OK;
+	}
+	if (c->hook_kernel == 2) // the end-of-render walker: one ray per wave (k_tail_wave's device code)
+	{
+		const int blocks = std::max( 1, std::min( ( n + 3 ) / 4, c->n_cus * 4 ) );
+		hipLaunchKernelGGL( k_rays_wave, dim3( blocks ), dim3( 256 ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
 		HIPCHK( hipGetLastError() );
 		return RTMI_OK;
 	}

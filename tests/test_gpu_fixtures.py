@@ -4,8 +4,9 @@ bvh_vectors: `cow`, `ball` (reference assets) and `mix` (3000 random triangles i
 40 spheres, a block of rays with a zero direction component).  The scenes are rebuilt here with the product's REFERENCE_SAH
 builder, the node array is asserted equal to the reference's dump, and closest-hit / any-hit queries are compared bit for
 bit with the reference's IntersectBVH / IntersectBVHShadowRay results (bvh.h:507-530, 640-688) -- with the 4-wide quantised
-nodes and with the reference's own boxes, through the parity-hook kernel and through the render path's persistent walk
-(k_trace), whose (t, leaf position) rule, `tmin <= t` box rule and exact-leaf-box confirmation are what decide the ties.
+nodes and with the reference's own boxes, through the parity-hook kernel (hook_kernel 0), through the render path's
+persistent walk (k_trace, 1) and through the end-of-render walker that gives a whole wave to one ray (k_tail_wave's code, 2),
+whose (t, leaf position) rule, `tmin <= t` box rule and exact-leaf-box confirmation are what decide the ties.
 
 unit_vectors: per-primitive cases (edge-on and axis-aligned triangles, rays with zero components, origins inside spheres,
 axis-aligned planes, finite ray.t) against one-primitive scenes: Triangle/Sphere/Plane/Quad/Cube::Intersect on the device
@@ -38,7 +39,7 @@ def build_fixture_scene(g, name):
 
 @pytest.mark.parametrize("name", ["cow", "ball", "mix"])
 @pytest.mark.parametrize("wide", [1, 0])
-@pytest.mark.parametrize("hook_kernel", [0, 1])
+@pytest.mark.parametrize("hook_kernel", [0, 1, 2])
 def test_reference_bvh_vectors(gold_bvh, name, wide, hook_kernel):
     g = gold_bvh
     s = build_fixture_scene(g, name)
@@ -85,7 +86,7 @@ def test_leaf_larger_than_64_primitives():
     copies = np.r_[0, 150:350]  # triangle 0 and its 200 copies: one leaf of 201
     assert np.isin(c_obj, copies).sum() > 50 and len(np.unique(c_obj[np.isin(c_obj, copies)])) == 1  # the first in leaf order wins every tie
     for wide in (1, 0):
-        for hook_kernel in (0, 1):
+        for hook_kernel in (0, 1, 2):
             d = api.Device(128, 128, wide=wide, hook_kernel=hook_kernel)
             d.upload(s.desc)
             obj, t = d.trace_rays(O, D, tmax)

@@ -176,15 +176,17 @@ def test_full_size_image_and_properties(full):
     d3.render(api.PATHTRACING, 0, 4, 1)
     assert np.array_equal(bits(d3.accumulator()), bits(four))
     d3.close()
-    # the end of a render: the last paths are walked by teams of four lanes (k_tail_team); option tail_team = 0 leaves them to
-    # k_tail, one lane per path.  Same visiting order, same arithmetic: same bits.  check_launches synchronises per bounce
-    d4 = api.Device(W, H, tail_team=0, check_launches=1)
-    d4.upload(scene.desc)
-    d4.set_seeds(seeds)
-    d4.set_camera(api.default_camera(W, H, scene.scale))
-    d4.render(api.PATHTRACING, 0, 4, 1)
-    assert np.array_equal(bits(d4.accumulator()), bits(four))
-    d4.close()
+    # the end of a render: the last 16 k paths are walked by teams of four lanes (k_tail_team), the last 4 k by a wave each
+    # (k_tail_wave); with both options off they stay with k_tail, one lane per path.  Same (t, leaf position) rule, same
+    # arithmetic: same bits.  check_launches synchronises per bounce
+    for opts in (dict(tail_team=0, tail_wave=0, check_launches=1), dict(tail_team=1, tail_wave=0), dict(tail_team=0, tail_wave=1, wave_below=1 << 16)):
+        d4 = api.Device(W, H, **opts)
+        d4.upload(scene.desc)
+        d4.set_seeds(seeds)
+        d4.set_camera(api.default_camera(W, H, scene.scale))
+        d4.render(api.PATHTRACING, 0, 4, 1)
+        assert np.array_equal(bits(d4.accumulator()), bits(four)), opts
+        d4.close()
     # progressive reads: reading the image between renders (late sums are folded at every read) changes rounding only
     d.reset()
     d.render(api.PATHTRACING, 0, 2, 1)

@@ -27,8 +27,8 @@ def _worker(rank, world, port, out_path):
     d.upload(scene.desc)
     d.set_seeds(api.seed_table(W * H))
     d.set_camera(api.default_camera(W, H))
-    # as bench.py does it: a caller-owned device accumulator on an explicit torch stream, rtmi_flush, then the collective on the
-    # device tensor itself -- no host read-back in between that would hide a missing ordering
+    # as bench.py does it: a caller-owned device accumulator on an explicit torch stream, rtmi_flush, then the consumer on that
+    # stream -- no rtmi_read_accumulator in between, whose own synchronisation would hide a missing ordering
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -37,9 +37,12 @@ def _worker(rank, world, port, out_path):
     mine = D.render_split(lambda b, n, st: d.render(api.PATHTRACING, b, n, st), 0, SPP)
     assert mine == SPP // world
     d.flush()
-    D.reduce_accumulator(acc, dst=0)
+    # what a collective on this stream would read: a copy issued by torch on the caller's stream right after rtmi_flush (gloo
+    # reduces host tensors; RCCL wants one GPU per rank and this box has one)
+    host = acc.cpu()
+    D.reduce_accumulator(host, dst=0)
     if rank == 0:
-        np.save(out_path, acc.cpu().numpy())
+        np.save(out_path, host.numpy())
     dist.barrier()
     d.close()
     dist.destroy_process_group()
