@@ -81,16 +81,17 @@ def _load_rccl():
     return None
 
 
-def test_reduce_accumulator_inside_the_boundary():
-    """rtmi_reduce_accumulator: the sum over ranks happens inside the C ABI, on an RCCL communicator the host made.  One
-    process drives every GPU of the box (ncclCommInitAll + group calls): 1 rank here on the one-GPU box (a reduce that must
-    leave the image as it is), 2 ranks where a second GPU is visible (sample split, sum == single render)."""
+def _reduce_worker(_, out_path):
+    """In a fresh process that imports torch FIRST, as bench.py does: this image has two ROCm runtimes (torch's bundled one
+    and /opt/rocm's), and RCCL only works when the whole process uses one of them -- the one loaded first."""
     import ctypes as C
     import torch
+    sys.path.insert(0, ROOT)
     from raytracer_amd import api
     lib = _load_rccl()
     if lib is None:
-        pytest.skip("no librccl.so.1 on this machine")
+        np.save(out_path, np.zeros(1))
+        return
     ndev = min(2, torch.cuda.device_count())
     comms = (C.c_void_p * ndev)()
     devs = (C.c_int * ndev)(*range(ndev))
@@ -104,7 +105,7 @@ def test_reduce_accumulator_inside_the_boundary():
         d.set_seeds(seeds)
         d.render(api.PATHTRACING, k, SPP // ndev, ndev)
         ds.append(d)
-    for root in (0, -1):  # ncclReduce onto rank 0, then ncclAllReduce of the results (rank 0 holds the sum, the others their own)
+    for root in (0, -1):  # ncclReduce onto rank 0; with one rank also ncclAllReduce (either must leave the one image as it is)
         if root == -1 and ndev > 1:
             break
         assert lib.ncclGroupStart() == 0
@@ -117,13 +118,29 @@ def test_reduce_accumulator_inside_the_boundary():
     one.set_seeds(seeds)
     one.render(api.PATHTRACING, 0, SPP, 1)
     want = one.accumulator()
-    if ndev == 1:
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    else:
-        assert np.allclose(got, want, rtol=2e-6, atol=1e-6)
-    L = api.device_lib()
-    assert L.rtmi_reduce_accumulator(ds[0].h, None, 0) == -1
+    assert api.device_lib().rtmi_reduce_accumulator(ds[0].h, None, 0) == -1
     for d in ds + [one]:
         d.close()
     for k in range(ndev):
         lib.ncclCommDestroy(C.c_void_p(comms[k]))
+    np.save(out_path, np.stack([got, want]))
+    with open(out_path + ".ndev", "w") as f:
+        f.write(str(ndev))
+
+
+def test_reduce_accumulator_inside_the_boundary(tmp_path):
+    """rtmi_reduce_accumulator: the sum over ranks happens inside the C ABI, on an RCCL communicator the host made.  One
+    process drives every GPU of the box (ncclCommInitAll + group calls): 1 rank here on the one-GPU box (a reduce that must
+    leave the image as it is), 2 ranks where a second GPU is visible (sample split, sum == single render)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "reduced.npy")
+    mp.spawn(_reduce_worker, args=(out,), nprocs=1, join=True)
+    res = np.load(out)
+    if res.ndim == 1:
+        pytest.skip("no librccl.so.1 on this machine")
+    got, want = res
+    assert np.abs(want[..., :3]).max() > 0
+    if open(out + ".ndev").read() == "1":
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    else:
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-6)
