@@ -160,6 +160,14 @@ int rtmi_render( rtmi_ctx*, int mode, int sample_begin, int sample_count, int sa
 int rtmi_trace_primary( rtmi_ctx*, int32_t* prim_id_out, float* t_out );
 int rtmi_trace_rays( rtmi_ctx*, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* prim_id_out, float* t_out );
 
+/* No counterpart in the reference.  rtmi_trace_rays for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same kernels, same results, but the rays
+ * are staged in a fixed device array that is part of the library's image (9 MB per GPU, held until the process ends)
+ * instead of memory the handle allocates.  At most RTMI_NOALLOC_MAX_RAYS rays per call (more: RTMI_ERR_INVALID).  The array
+ * is shared by every call on that GPU: calls that overlap on one GPU race. */
+#define RTMI_NOALLOC_MAX_RAYS ( 1 << 18 )
+int rtmi_trace_rays_noalloc( rtmi_ctx*, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* prim_id_out, float* t_out );
+
 /* Replaces Finalize + deviceBuffer->CopyFromDevice (renderer.cpp:553-556; RGBF32_to_RGB8, precomp.h:431-465) and,
  * when fx != NULL, the PostProcessing passes (postprocessing.h:16-99).  frames <= 0 selects the one-argument
  * RGBF32_to_RGB8 (Whitted path). */

@@ -20,6 +20,7 @@ ASSETS = os.path.join(ROOT, "assets")
 NORMAL, DISTANCE, ALBEDO, RAYTRACING, PATHTRACING = range(5)
 DIFFUSE, MIRROR, GLASS, SUBSTANCE, LIGHT = range(5)
 REFERENCE_SAH, BINNED_SAH = 0, 1
+NOALLOC_MAX_RAYS = 1 << 18  # RTMI_NOALLOC_MAX_RAYS
 # GLFW key codes the reference's Renderer::KeyDown / KeyUp handle (renderer.cpp:368-441)
 KEY_A, KEY_D, KEY_E, KEY_Q, KEY_S, KEY_W, KEY_RIGHT, KEY_LEFT, KEY_DOWN, KEY_UP = 65, 68, 69, 81, 83, 87, 262, 263, 264, 265
 
@@ -126,7 +127,7 @@ def device_lib():
         for name in ("rtmi_create", "rtmi_destroy", "rtmi_set_stream", "rtmi_upload_scene", "rtmi_set_camera", "rtmi_set_seeds", "rtmi_reset_accumulator",
                      "rtmi_set_accumulator", "rtmi_render", "rtmi_trace_primary", "rtmi_trace_rays", "rtmi_finalize", "rtmi_postprocess",
                      "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_flush", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats",
-                     "rtmi_use_own_stream", "rtmi_set_option", "rtmi_get_option", "rtmi_reduce_accumulator"):
+                     "rtmi_use_own_stream", "rtmi_set_option", "rtmi_get_option", "rtmi_reduce_accumulator", "rtmi_trace_rays_noalloc"):
             getattr(L, name).restype = C.c_int
         L.rtmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.rtmi_destroy.argtypes = [C.c_void_p]
@@ -139,6 +140,7 @@ def device_lib():
         L.rtmi_render.argtypes = [C.c_void_p] + [C.c_int] * 6
         L.rtmi_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtmi_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rtmi_trace_rays_noalloc.argtypes = L.rtmi_trace_rays.argtypes
         L.rtmi_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(PostFx)]
         L.rtmi_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(PostFx)]
         L.rtmi_read_accumulator.argtypes = [C.c_void_p, C.c_void_p]
@@ -425,6 +427,17 @@ class Device:
         obj = np.zeros(n, np.int32)
         t = np.zeros(n, np.float32)
         self._chk(self.L.rtmi_trace_rays(self.h, n, _ptr(O), _ptr(D), _ptr(tmax), int(any_hit), _ptr(obj), _ptr(t)))
+        return obj, t
+
+    def trace_rays_noalloc(self, O, D, tmax, any_hit=False):
+        """rtmi_trace_rays_noalloc: no device allocation, at most NOALLOC_MAX_RAYS rays"""
+        O = np.ascontiguousarray(O, np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, np.float32).reshape(-1, 3)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = len(O)
+        obj = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float32)
+        self._chk(self.L.rtmi_trace_rays_noalloc(self.h, n, _ptr(O), _ptr(D), _ptr(tmax), int(any_hit), _ptr(obj), _ptr(t)))
         return obj, t
 
     def accumulator(self):

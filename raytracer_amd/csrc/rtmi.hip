@@ -1620,6 +1620,31 @@ struct rtmi_ctx
 	std::vector<hipEvent_t> ev_pool;
 };
 
+// ---- rtmi_trace_rays_noalloc: staging in a file-scope device array instead of allocated memory --------------------------
+// 36 bytes per ray (origin, direction, tmax in; object id, distance out).  Every GPU the library runs on holds its own copy
+// of the array, at its own address, until the process ends.  In host code the NAME is only a handle for
+// hipGetSymbolAddress: the address kernels and copies use is looked up once per device (scratch_address, under the
+// device being current) and kept.
+#define RTMI_NOALLOC_MAX_RAYS ( 1 << 18 )
+static __device__ __align__( 256 ) unsigned char scratch[(size_t)RTMI_NOALLOC_MAX_RAYS * 36];
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[64] = {};
+static hipError_t scratch_address( int device, void** out ) // the caller has made `device` current
+{
+	std::lock_guard<std::mutex> lock( g_scratch_mutex );
+	*out = 0;
+	if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+	if (!g_scratch_ptr[device])
+	{
+		void* p = 0;
+		const hipError_t e = hipGetSymbolAddress( &p, HIP_SYMBOL( scratch ) );
+		if (e != hipSuccess) return e;
+		g_scratch_ptr[device] = p;
+	}
+	*out = g_scratch_ptr[device];
+	return hipSuccess;
+}
+
 #define HIPCHK( call )                                                                                                         \
 	do {                                                                                                                       \
 		hipError_t e_ = ( call );                                                                                              \
@@ -1985,6 +2010,7 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	if (hipSetDevice( device_id ) != hipSuccess) return bail( RTMI_ERR_HIP );
 	if (hipStreamCreateWithFlags( &c->own_stream, hipStreamNonBlocking ) != hipSuccess) return bail( RTMI_ERR_HIP );
 	c->stream = c->own_stream;
+	if (scratch_address( device_id, &c->noalloc_scratch ) != hipSuccess) { (void)hipStreamDestroy( c->own_stream ); return bail( RTMI_ERR_HIP ); }
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties( &prop, device_id ) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
@@ -2817,6 +2843,36 @@ int rtmi_trace_rays( rtmi_ctx* c, int n, const float* O3, const float* D3, const
 	HIPCHK( hipMemcpyAsync( dD, D3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
 	HIPCHK( hipMemcpyAsync( dT, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream ) );
 	if (( r = launch_trace_rays( c, n, dO, dD, dT, any_hit, dobj, dt ) )) return r;
+	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e3 = hipStreamSynchronize( c->stream );
+	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
+	return RTMI_OK;
+}
+
+// rtmi_trace_rays without any allocation: the rays are staged in this device's copy of `scratch` (through the address kept at
+// rtmi_create, never the array's name).  Nothing in the array has to start at zero: the copies fill the inputs of rays
+// 0 .. n-1 and the kernel writes both outputs of every one of them, so what an earlier, larger call left behind is never read.
+// Calls that overlap on one GPU (two handles, two host threads) share the array and race.
+int rtmi_trace_rays_noalloc( rtmi_ctx* c, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* obj_out, float* t_out )
+{
+	if (!c || n < 0 || ( n && ( !O3 || !D3 || !tmax || !obj_out || !t_out ) )) return RTMI_ERR_INVALID;
+	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_trace_rays_noalloc before rtmi_upload_scene" );
+	if (n > RTMI_NOALLOC_MAX_RAYS) return fail( c, RTMI_ERR_INVALID, "rtmi_trace_rays_noalloc: at most " + std::to_string( RTMI_NOALLOC_MAX_RAYS ) + " rays per call (use rtmi_trace_rays)" );
+	if (n == 0) return RTMI_OK;
+	HIPCHK( hipSetDevice( c->device ) );
+	float* dO = (float*)c->noalloc_scratch, *dD = dO + 3 * (size_t)RTMI_NOALLOC_MAX_RAYS, *dT = dD + 3 * (size_t)RTMI_NOALLOC_MAX_RAYS, *dt = dT + RTMI_NOALLOC_MAX_RAYS;
+	int* dobj = (int*)( dt + RTMI_NOALLOC_MAX_RAYS );
+	HIPCHK( hipMemcpyAsync( dO, O3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dD, D3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dT, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream ) );
+	// the same kernels as rtmi_trace_rays; option hook_kernel = 1 (the render path's queues) needs a render batch's buffers,
+	// which may have to be allocated, so it is served by kernel 0 here
+	if (c->hook_kernel == 2)
+		hipLaunchKernelGGL( k_rays_wave, dim3( std::max( 1, std::min( ( n + 3 ) / 4, c->n_cus * 4 ) ) ), dim3( 256 ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+	else
+		hipLaunchKernelGGL( k_trace_rays, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+	HIPCHK( hipGetLastError() );
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e3 = hipStreamSynchronize( c->stream );
