@@ -177,6 +177,7 @@ def host_lib():
         L.rth_scene_add_quad.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.POINTER(Material)]
         L.rth_scene_add_cube.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Material)]
         L.rth_scene_load_obj.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Material), C.c_float, C.c_float, C.c_float]
+        L.rth_scene_load_obj_mtl.argtypes = L.rth_scene_load_obj.argtypes
         L.rth_scene_load_texture_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
         L.rth_scene_finalize.argtypes = [C.c_void_p, C.c_int]
         L.rth_scene_desc.argtypes = [C.c_void_p]
@@ -272,6 +273,11 @@ class HostScene:
 
     def load_obj(self, path, mat, offset=(0, 0, 0)):
         if self.L.rth_scene_load_obj(self.h, path.encode(), C.byref(mat), *[float(x) for x in offset]) != 0:
+            raise RtmiError("cannot load " + path)
+
+    def load_obj_with_materials(self, path, fallback, offset=(0, 0, 0)):
+        """LoadObject with the file's usemtl / mtllib materials instead of one Material per file"""
+        if self.L.rth_scene_load_obj_mtl(self.h, path.encode(), C.byref(fallback), *[float(x) for x in offset]) != 0:
             raise RtmiError("cannot load " + path)
 
     def load_logo(self, assets=ASSETS):

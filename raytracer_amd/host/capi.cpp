@@ -47,6 +47,10 @@ int rth_scene_load_obj( void* s, const char* path, const rth_material* m, float 
 {
 	return ( (Scene*)s )->LoadObject( path, to_mat( m ), float3( ox, oy, oz ) ) ? 0 : -1;
 }
+int rth_scene_load_obj_mtl( void* s, const char* path, const rth_material* fallback, float ox, float oy, float oz )
+{
+	return ( (Scene*)s )->LoadObjectWithMaterials( path, to_mat( fallback ), float3( ox, oy, oz ) ) ? 0 : -1;
+}
 int rth_scene_load_texture_raw( void* s, const char* path, int w, int h ) { return ( (Scene*)s )->LoadTextureRaw( path, w, h ) ? 0 : -1; }
 void rth_scene_finalize( void* s, int builder ) { ( (Scene*)s )->Finalize( (BVH::Builder)builder ); }
 const rtmi_scene_desc* rth_scene_desc( void* s ) { return ( (Scene*)s )->Desc(); }

@@ -1,8 +1,13 @@
 // scene.cpp -- host scene container (see scene.h).  Build with -O2 -ffp-contract=off.
 #include "scene.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace rtmi {
 
@@ -131,51 +136,218 @@ static bool ParseReal( const char*& s, float& out )
 	return true;
 }
 
-bool Scene::LoadObject( const std::string& file, const Material& material, float3 transform )
+// ---- OBJ ingest (Scene::LoadObject, scene.h:222-291, which goes through tinyobjloader v2.0.0) ------------------------------
+// The whole file is read into memory and cut into chunks at line ends, one per thread.  Pass 1 counts, per chunk, the
+// vertices, the triangles its faces produce and its `usemtl` statements; prefix sums give every chunk its place in the
+// global arrays (file order is kept: scene.h:246-268 walks shapes and faces in file order) and the material in force at its
+// first line.  Pass 2a parses the vertices, pass 2b the faces.  Decimal text -> float is ParseReal above (tinyobj's own
+// algorithm), a quad is split along its shorter diagonal as tinyobj does (tiny_obj_loader.h:1485-1580); polygons with more
+// than four corners are fanned (tinyobj ear-clips them; the reference's assets hold triangles only).
+namespace {
+struct ObjChunk { const char* b, *e; size_t nv = 0, ntri = 0, v0 = 0, t0 = 0; std::vector<std::pair<size_t, std::string>> mtl; std::string mtlAtStart; };
+inline const char* line_end( const char* p, const char* e ) { while (p < e && *p != '\n') p++; return p; }
+inline const char* skip_ws( const char* s ) { while (*s == ' ' || *s == '\t') s++; return s; }
+inline bool is_ws_or_end( char c ) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == 0; }
+// the vertex index of one face corner "v", "v/vt", "v/vt/vn", "v//vn" (1-based; negative = relative to the vertices read so far)
+inline bool corner_index( const char*& s, const char* e, long long nvBefore, long long& out )
+{
+	s = skip_ws( s );
+	if (s >= e || *s == '\r' || *s == '\n') return false;
+	char* end;
+	const long i = strtol( s, &end, 10 );
+	if (end == s) return false;
+	out = i > 0 ? i - 1 : nvBefore + i;
+	s = end;
+	while (s < e && !is_ws_or_end( *s )) s++; // skip /vt/vn
+	return true;
+}
+std::string token_after( const char* s, const char* e )
+{
+	s = skip_ws( s );
+	const char* t = s;
+	while (t < e && *t != '\r' && *t != '\n') t++;
+	while (t > s && ( t[-1] == ' ' || t[-1] == '\t' )) t--;
+	return std::string( s, t );
+}
+} // namespace
+
+// Wavefront .mtl -> Material (no reference counterpart: the reference parses the .mtl through tinyobj and then ignores it,
+// scene.h:266).  Kd -> color, Ke -> emission, Ni -> refractive index, Tf -> Beer absorption -ln(Tf) per unit length.
+// Type: LIGHT if Ke > 0; else GLASS for illum 4, 6, 7, 9 or d / Tr making it transparent; else MIRROR for illum 3, 5, 8;
+// else DIFFUSE.
+bool Scene::LoadMaterialLibrary( const std::string& file, std::vector<std::pair<std::string, Material>>& out )
 {
 	std::ifstream f( file );
-	if (!f) { fprintf( stderr, "rtmi::Scene::LoadObject: cannot open %s\n", file.c_str() ); return false; }
-	std::vector<float> v; // xyz
-	std::string line;
-	size_t before = vt.size();
+	if (!f) return false;
+	std::string line, name;
+	Material m;
+	int illum = 2;
+	float d = 1;
+	bool have = false;
+	auto flush = [&]() {
+		if (!have) return;
+		const bool emits = m.emission.x > 0 || m.emission.y > 0 || m.emission.z > 0;
+		m.type = emits ? Material::MaterialType::LIGHT : ( illum == 4 || illum == 6 || illum == 7 || illum == 9 || d < 1 ) ? Material::MaterialType::GLASS
+			: ( illum == 3 || illum == 5 || illum == 8 ) ? Material::MaterialType::MIRROR : Material::MaterialType::DIFFUSE;
+		out.push_back( { name, m } ); };
 	while (std::getline( f, line ))
 	{
-		const char* s = line.c_str();
-		while (*s == ' ' || *s == '\t') s++;
-		if (s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' ))
+		const char* s = skip_ws( line.c_str() ), *e = line.c_str() + line.size();
+		auto three = [&]( const char* p, float3& v ) { float x = 0, y = 0, z = 0; if (ParseReal( p, x )) { y = z = x; if (ParseReal( p, y )) ParseReal( p, z ); else y = x; } v = float3( x, y, z ); };
+		if (!strncmp( s, "newmtl", 6 ) && is_ws_or_end( s[6] )) { flush(); name = token_after( s + 6, e ), m = Material(), m.color = float3( 0.93f ), illum = 2, d = 1, have = true; }
+		else if (!strncmp( s, "Kd", 2 ) && is_ws_or_end( s[2] )) three( s + 2, m.color );
+		else if (!strncmp( s, "Ke", 2 ) && is_ws_or_end( s[2] )) three( s + 2, m.emission );
+		else if (!strncmp( s, "Tf", 2 ) && is_ws_or_end( s[2] )) { float3 tf; three( s + 2, tf ); m.absorption = float3( -logf( tmax( tf.x, 1e-6f ) ), -logf( tmax( tf.y, 1e-6f ) ), -logf( tmax( tf.z, 1e-6f ) ) ); }
+		else if (!strncmp( s, "Ni", 2 ) && is_ws_or_end( s[2] )) { const char* p = s + 2; ParseReal( p, m.refractive_index ); }
+		else if (!strncmp( s, "illum", 5 ) && is_ws_or_end( s[5] )) illum = atoi( s + 5 );
+		else if (s[0] == 'd' && is_ws_or_end( s[1] )) { const char* p = s + 1; ParseReal( p, d ); }
+		else if (!strncmp( s, "Tr", 2 ) && is_ws_or_end( s[2] )) { const char* p = s + 2; float tr = 0; if (ParseReal( p, tr )) d = 1 - tr; }
+	}
+	flush();
+	return true;
+}
+
+bool Scene::LoadObject( const std::string& file, const Material& material, float3 transform ) { return LoadObjectImpl( file, material, transform, false ); }
+bool Scene::LoadObjectWithMaterials( const std::string& file, const Material& fallback, float3 transform ) { return LoadObjectImpl( file, fallback, transform, true ); }
+
+bool Scene::LoadObjectImpl( const std::string& file, const Material& material, float3 transform, bool useMtl )
+{
+	std::string text;
+	{
+		FILE* f = fopen( file.c_str(), "rb" );
+		if (!f) { fprintf( stderr, "rtmi::Scene::LoadObject: cannot open %s\n", file.c_str() ); return false; }
+		fseek( f, 0, SEEK_END );
+		const long size = ftell( f );
+		fseek( f, 0, SEEK_SET );
+		text.resize( size > 0 ? (size_t)size : 0 );
+		const size_t got = text.empty() ? 0 : fread( &text[0], 1, text.size(), f );
+		fclose( f );
+		if (got != text.size()) return false;
+	}
+	const char* B = text.c_str(), *E = B + text.size();
+	int nth = 1;
+#ifdef _OPENMP
+	nth = std::max( 1, std::min( omp_get_max_threads(), (int)( text.size() / ( 1u << 20 ) ) + 1 ) );
+#endif
+	std::vector<ObjChunk> ch( nth );
+	for (int k = 0; k < nth; k++)
+	{
+		const char* b = k == 0 ? B : ch[k - 1].e;
+		const char* e = k == nth - 1 ? E : line_end( std::max( b, B + text.size() * (size_t)( k + 1 ) / nth ), E );
+		if (e < E) e++; // past the newline
+		ch[k].b = b, ch[k].e = e;
+	}
+	std::vector<std::string> mtllibs;
+	// pass 1: counts
+#pragma omp parallel for schedule( static, 1 ) num_threads( nth )
+	for (int k = 0; k < nth; k++)
+	{
+		ObjChunk& c = ch[k];
+		for (const char* p = c.b; p < c.e; )
 		{
-			s += 2;
-			float x = 0, y = 0, z = 0;
-			ParseReal( s, x ), ParseReal( s, y ), ParseReal( s, z );
-			v.push_back( x ), v.push_back( y ), v.push_back( z );
-		}
-		else if (s[0] == 'f' && ( s[1] == ' ' || s[1] == '\t' ))
-		{
-			s += 2;
-			std::vector<int> idx;
-			while (*s)
+			const char* le = line_end( p, c.e );
+			const char* s = skip_ws( p );
+			if (s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' )) c.nv++;
+			else if (s[0] == 'f' && ( s[1] == ' ' || s[1] == '\t' ))
 			{
-				while (*s == ' ' || *s == '\t' || *s == '\r') s++;
-				if (!*s) break;
-				char* end;
-				long i = strtol( s, &end, 10 );
-				if (end == s) break;
-				const int nv = (int)( v.size() / 3 );
-				idx.push_back( i > 0 ? (int)i - 1 : nv + (int)i ); // 1-based, negative = relative to the end
-				s = end;
-				while (*s && *s != ' ' && *s != '\t') s++; // skip /vt/vn
+				int corners = 0;
+				long long dummy;
+				for (const char* q = s + 2; corner_index( q, le, 0, dummy ); ) corners++;
+				if (corners >= 3) c.ntri += (size_t)( corners - 2 );
 			}
-			// faces with more than 3 corners are fanned (the reference's assets are all triangles)
-			for (size_t k = 2; k < idx.size(); k++)
-			{
-				const int a = idx[0], b = idx[k - 1], c = idx[k];
-				if (a < 0 || b < 0 || c < 0 || (size_t)a * 3 + 2 >= v.size() || (size_t)b * 3 + 2 >= v.size() || (size_t)c * 3 + 2 >= v.size()) return false;
-				const float3 vx( v[3 * a], v[3 * a + 1], v[3 * a + 2] ), vy( v[3 * b], v[3 * b + 1], v[3 * b + 2] ), vz( v[3 * c], v[3 * c + 1], v[3 * c + 2] );
-				vt.push_back( Triangle( 0, vx + transform, vy + transform, vz + transform, material ) ); // scene.h:266
-			}
+			else if (useMtl && !strncmp( s, "usemtl", 6 ) && is_ws_or_end( s[6] )) c.mtl.push_back( { c.ntri, token_after( s + 6, le ) } );
+			p = le + 1;
 		}
 	}
-	return vt.size() > before;
+	if (useMtl) // (mtllib lines are rare: one sequential scan for them)
+		for (const char* p = B; p < E; )
+		{
+			const char* le = line_end( p, E );
+			const char* s = skip_ws( p );
+			if (!strncmp( s, "mtllib", 6 ) && is_ws_or_end( s[6] )) mtllibs.push_back( token_after( s + 6, le ) );
+			p = le + 1;
+		}
+	size_t nv = 0, ntri = 0;
+	std::string cur;
+	for (int k = 0; k < nth; k++)
+	{
+		ch[k].v0 = nv, ch[k].t0 = ntri, ch[k].mtlAtStart = cur;
+		nv += ch[k].nv, ntri += ch[k].ntri;
+		if (!ch[k].mtl.empty()) cur = ch[k].mtl.back().second;
+	}
+	if (ntri == 0) return false;
+	// materials by name
+	std::vector<std::pair<std::string, Material>> lib;
+	if (useMtl)
+	{
+		const size_t slash = file.find_last_of( '/' );
+		const std::string dir = slash == std::string::npos ? "" : file.substr( 0, slash + 1 );
+		for (const std::string& m : mtllibs) LoadMaterialLibrary( dir + m, lib );
+	}
+	auto material_named = [&]( const std::string& name ) -> const Material& {
+		for (const auto& m : lib) if (m.first == name) return m.second;
+		return material; };
+	// pass 2a: vertices
+	std::vector<float> v( nv * 3 );
+#pragma omp parallel for schedule( static, 1 ) num_threads( nth )
+	for (int k = 0; k < nth; k++)
+	{
+		size_t at = ch[k].v0;
+		for (const char* p = ch[k].b; p < ch[k].e; )
+		{
+			const char* le = line_end( p, ch[k].e );
+			const char* s = skip_ws( p );
+			if (s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' ))
+			{
+				s += 2;
+				float x = 0, y = 0, z = 0;
+				ParseReal( s, x ), ParseReal( s, y ), ParseReal( s, z );
+				v[3 * at] = x, v[3 * at + 1] = y, v[3 * at + 2] = z, at++;
+			}
+			p = le + 1;
+		}
+	}
+	// pass 2b: faces -> triangles, in file order
+	const size_t before = vt.size();
+	vt.resize( before + ntri );
+	bool bad = false;
+#pragma omp parallel for schedule( static, 1 ) num_threads( nth )
+	for (int k = 0; k < nth; k++)
+	{
+		size_t at = before + ch[k].t0, seenV = ch[k].v0, nextMtl = 0;
+		const Material* mat = useMtl && !ch[k].mtlAtStart.empty() ? &material_named( ch[k].mtlAtStart ) : &material;
+		std::vector<long long> idx;
+		for (const char* p = ch[k].b; p < ch[k].e; )
+		{
+			const char* le = line_end( p, ch[k].e );
+			const char* s = skip_ws( p );
+			if (s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' )) seenV++;
+			else if (s[0] == 'f' && ( s[1] == ' ' || s[1] == '\t' ))
+			{
+				while (nextMtl < ch[k].mtl.size() && ch[k].mtl[nextMtl].first <= at - before - ch[k].t0) mat = &material_named( ch[k].mtl[nextMtl++].second );
+				idx.clear();
+				long long i;
+				for (const char* q = s + 2; corner_index( q, le, (long long)seenV, i ); ) idx.push_back( i );
+				auto P = [&]( long long a ) { return float3( v[3 * a], v[3 * a + 1], v[3 * a + 2] ); };
+				auto ok = [&]( long long a ) { return a >= 0 && (size_t)a < nv; };
+				auto emit = [&]( long long a, long long b, long long c ) {
+					if (!ok( a ) || !ok( b ) || !ok( c )) { bad = true; a = b = c = 0; }
+					vt[at++] = Triangle( 0, P( a ) + transform, P( b ) + transform, P( c ) + transform, *mat ); }; // scene.h:266
+				if (idx.size() == 4 && ok( idx[0] ) && ok( idx[1] ) && ok( idx[2] ) && ok( idx[3] ))
+				{
+					// tinyobj: the shorter diagonal splits the quad (tiny_obj_loader.h:1537-1580), binary32 arithmetic
+					const float3 e02 = P( idx[2] ) - P( idx[0] ), e13 = P( idx[3] ) - P( idx[1] );
+					const float sqr02 = e02.x * e02.x + e02.y * e02.y + e02.z * e02.z, sqr13 = e13.x * e13.x + e13.y * e13.y + e13.z * e13.z;
+					if (sqr02 < sqr13) emit( idx[0], idx[1], idx[2] ), emit( idx[0], idx[2], idx[3] );
+					else emit( idx[0], idx[1], idx[3] ), emit( idx[1], idx[2], idx[3] );
+				}
+				else for (size_t c = 2; c < idx.size(); c++) emit( idx[0], idx[c - 1], idx[c] );
+			}
+			p = le + 1;
+		}
+	}
+	if (bad) { vt.resize( before ); return false; }
+	return true;
 }
 
 void Scene::Finalize( BVH::Builder builder )

@@ -8,6 +8,7 @@
 #include "bvh.h"
 #include "../../include/rtmi.h"
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace rtmi {
@@ -32,6 +33,10 @@ public:
 	void AddTriangles( const float* v9, size_t count, const Material& m, float3 offset = float3( 0 ) );
 	// scene.h:222-291: every face of every shape in file order, vertices + offset, one material per file
 	bool LoadObject( const std::string& file, const Material& m, float3 offset = float3( 0 ) );
+	// the same reader with per-material support (the reference parses the .mtl and ignores it): every `usemtl`
+	// group gets the Material built from its `newmtl` entry of the `mtllib` files, `fallback` where there is none
+	bool LoadObjectWithMaterials( const std::string& file, const Material& fallback, float3 offset = float3( 0 ) );
+	static bool LoadMaterialLibrary( const std::string& file, std::vector<std::pair<std::string, Material>>& out );
 	void SetTexture( const uint32_t* pixels, int w, int h );
 	bool LoadTextureRaw( const std::string& file, int w, int h ); // w*h little-endian 0x00RRGGBB words
 
@@ -69,6 +74,7 @@ public:
 	int tex_w = 0, tex_h = 0;
 
 private:
+	bool LoadObjectImpl( const std::string& file, const Material& m, float3 offset, bool useMtl );
 	void InitMaterials();
 	std::vector<Quad> vq;
 	std::vector<Sphere> vs;

@@ -164,3 +164,77 @@ def test_camera_mirror_matches_oracle_restatement():
     assert L.rth_camera_script(W, H, len(events), ev.ctypes.data, val.ctypes.data, got.ctypes.data, gm.ctypes.data) == len(cams)
     assert np.array_equal(got.view(np.uint32), cams.view(np.uint32)) and np.array_equal(gm, moved)
     assert moved.any() and not moved.all() and np.isfinite(cams).all() and len(cams) > 100
+
+
+def test_obj_with_materials_quads_and_index_forms(tmp_path):
+    """`usemtl` / `mtllib` -> per-triangle Materials (the reference parses the .mtl and ignores it, scene.h:266), a quad
+    split along its shorter diagonal as tinyobj does (tiny_obj_loader.h:1485-1580), v/vt/vn and negative indices, CRLF line ends"""
+    (tmp_path / "m.mtl").write_text("newmtl red\nKd 0.9 0.1 0.2\nillum 2\n\nnewmtl mirror\nKd 0.8 0.8 0.8\nillum 3\n"
+                                    "newmtl glass\nKd 1 1 1\nNi 1.52\nillum 7\nTf 0.5 0.25 1.0\nnewmtl lamp\nKe 2 2 2\nKd 1 1 1\n")
+    obj = ("mtllib m.mtl\r\n"
+           "v 0 0 0\r\nv 1 0 0\r\nv 1 1 0\r\nv 0 2 0\r\nv 0 0 1\r\nv 1 0 1\r\nv 0 1 1\r\n"
+           "vn 0 0 1\nvt 0 0\n"
+           "f 1 2 3\n"                    # before any usemtl: the fallback
+           "usemtl red\nf 1/1/1 2/1/1 3/1/1 4/1/1\n"   # quad: diagonals |p3-p1|^2 = 2, |p4-p2|^2 = 5 -> [0,1,2],[0,2,3]
+           "usemtl mirror\nf -3 -2 -1\n"
+           "usemtl glass\nf 5//1 6//1 7//1\n"
+           "usemtl unknown\nf 1 3 5\n"
+           "usemtl lamp\nf 2 4 6 7 5\n")   # pentagon: fanned into 3
+    (tmp_path / "t.obj").write_bytes(obj.encode())
+    fb = api.Material(api.DIFFUSE, (0.5, 0.5, 0.5))
+    s = api.HostScene()
+    s.load_obj_with_materials(str(tmp_path / "t.obj"), fb, (0.25, 0, 0))
+    s.finalize()
+    a = s.desc.arrays()
+    assert s.info()["triangles"] == 9
+    types = a["material_type"].tolist()
+    assert types == [api.DIFFUSE, api.DIFFUSE, api.DIFFUSE, api.MIRROR, api.GLASS, api.DIFFUSE, api.LIGHT, api.LIGHT, api.LIGHT]
+    assert np.allclose(a["albedo"][0, :3], 0.5) and np.allclose(a["albedo"][1, :3], (0.9, 0.1, 0.2)) and np.allclose(a["albedo"][5, :3], 0.5)
+    assert a["ior"][4] == np.float32(1.52) and np.allclose(a["absorption"][4, :3], -np.log(np.float32([0.5, 0.25, 1.0])), rtol=1e-6)
+    v = a["tri_verts"][:, :, :3] - np.float32([0.25, 0, 0])
+    P = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 2, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1]])
+    want = [(0, 1, 2), (0, 1, 2), (0, 2, 3), (4, 5, 6), (4, 5, 6), (0, 2, 4), (1, 3, 5), (1, 5, 6), (1, 6, 4)]
+    for k, tri in enumerate(want):
+        assert np.array_equal(v[k], P[list(tri)]), k
+    # the reference's own entry point: one Material per file whatever the file says
+    s2 = api.HostScene()
+    s2.load_obj(str(tmp_path / "t.obj"), fb)
+    s2.finalize()
+    assert set(s2.desc.arrays()["material_type"].tolist()) == {api.DIFFUSE} and s2.info()["triangles"] == 9
+    # a face that names a vertex that does not exist is refused, nothing is added
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
+    s3 = api.HostScene()
+    with pytest.raises(api.RtmiError):
+        s3.load_obj(str(tmp_path / "bad.obj"), fb)
+
+
+def test_obj_ingest_at_scale(tmp_path):
+    """the 1M-triangle scene of configs[2] through the OBJ path: written as text (rth_write_obj), read back by the chunk-parallel
+    reader (Scene::LoadObject): every vertex bit-identical, triangles in file order, with one thread as with many"""
+    import subprocess
+    import sys
+    import time
+    L = api.host_lib()
+    nu, nv = 5400, 31  # one knot of the 1M scene: 334 800 triangles; three of them in one file
+    n1 = nu * nv * 2
+    v9 = np.zeros((3 * n1, 9), np.float32)
+    for k, x in enumerate((-10.5, 0.0, 10.5)):
+        assert L.rth_torus_knot(nu, nv, 0.42 * 7, 0.17 * 7, 0.075 * 7, 2, 3, x, 0.0, 10.5, v9[k * n1:].ctypes.data) == n1
+    path = str(tmp_path / "knots1m.obj")
+    assert L.rth_write_obj(path.encode(), v9.ctypes.data, len(v9)) == 0
+    assert os.path.getsize(path) > 50e6
+    t0 = time.time()
+    s = api.HostScene()
+    s.load_obj(path, api.Material())
+    dt = time.time() - t0
+    s.finalize(api.BINNED_SAH)
+    got = s.desc.arrays()["tri_verts"][:, :, :3].reshape(-1, 9)
+    assert len(got) == 3 * n1 > 1000000 and np.array_equal(got.view(np.uint32), v9.view(np.uint32))
+    print("OBJ ingest: %d triangles, %.0f MB of text in %.2f s" % (len(got), os.path.getsize(path) / 1e6, dt))
+    # one thread reads the same bytes into the same triangles
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\nfrom raytracer_amd import api\n"
+            "s = api.HostScene(); s.load_obj(%r, api.Material()); s.finalize(api.BINNED_SAH)\n"
+            "print(hashlib.sha1(np.ascontiguousarray(s.desc.arrays()['tri_verts']).tobytes()).hexdigest())\n") % (ROOT, path)
+    one = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, check=True).stdout.strip()
+    import hashlib
+    assert one == hashlib.sha1(np.ascontiguousarray(s.desc.arrays()["tri_verts"]).tobytes()).hexdigest()

@@ -406,3 +406,47 @@ def test_full_size_64spp_rows(full):
     px = d.finalize(64)
     want = Oracle().finalize(ref[rows].reshape(-1, 4), 64).reshape(-1, W)
     assert (px[rows] != want).mean() < 1e-3  # RGB8 of two images that agree to 1e-5: a few values sit on a truncation boundary
+
+
+def test_obj_with_mtl_materials_renders_like_the_oracle(tmp_path):
+    """one OBJ file whose `usemtl` groups carry diffuse, mirror and glass materials (the .mtl the reference
+    would ignore) through LoadObjectWithMaterials -> per-primitive material arrays -> the device; image vs the oracle"""
+    L = api.host_lib()
+    nu, nv = 120, 12
+    n1 = nu * nv * 2
+    parts = []
+    for x in (-1.5, 0.0, 1.5):
+        v9 = np.zeros((n1, 9), np.float32)
+        assert L.rth_torus_knot(nu, nv, 0.42, 0.17, 0.075, 2, 3, x, 0.0, 1.5, v9.ctypes.data) == n1
+        parts.append(v9)
+    (tmp_path / "k.mtl").write_text("newmtl a\nKd 0.93 0.21 0.21\nillum 2\nnewmtl b\nKd 0.93 0.93 0.93\nillum 3\nnewmtl c\nKd 0.93 0.93 0.93\nNi 1.52\nillum 7\n")
+    with open(tmp_path / "k.obj", "w") as f:
+        f.write("mtllib k.mtl\n")
+        base = 0
+        for name, v9 in zip("abc", parts):
+            for p in v9.reshape(-1, 3):
+                f.write("v %.9g %.9g %.9g\n" % tuple(p))
+            f.write("usemtl %s\n" % name)
+            for k in range(len(v9)):
+                f.write("f %d %d %d\n" % (base + 3 * k + 1, base + 3 * k + 2, base + 3 * k + 3))
+            base += 3 * len(v9)
+    s = api.HostScene().make_room()
+    s.load_logo()
+    s.load_obj_with_materials(str(tmp_path / "k.obj"), api.Material())
+    s.finalize(api.BINNED_SAH)
+    mats = s.desc.arrays()["material_type"][7:]
+    assert np.array_equal(np.unique(mats, return_counts=True)[1], [n1, n1, n1]) and mats[0] == api.DIFFUSE and mats[n1] == api.MIRROR and mats[-1] == api.GLASS
+    W, H = 160, 90
+    cam, seeds = api.default_camera(W, H), api.seed_table(W * H)
+    orc = Oracle(s.desc)
+    d = api.Device(W, H)
+    d.upload(s.desc)
+    d.set_seeds(seeds)
+    obj, t = d.trace_primary()
+    o_obj, o_t = orc.primary_hits(W, H, cam)
+    assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+    hit = s.desc.arrays()["material_type"][obj[obj >= 7]]
+    assert set(np.unique(hit).tolist()) == {api.DIFFUSE, api.MIRROR, api.GLASS}
+    d.render(api.PATHTRACING, 0, 4, 1)
+    assert rmse(d.accumulator()[..., :3], orc.sample(W, H, cam, seeds, 0, 4)[..., :3]) <= 4e-5
+    d.close()
