@@ -118,7 +118,7 @@ def device_lib():
     """librtmi.so; raises RtmiError if it was not built."""
     global _dev
     if _dev is None:
-        path = os.path.join(_PKG, "librtmi.so")
+        path = os.path.join(_PKG, os.environ.get("RTMI_LIBRARY", "librtmi.so"))  # (experimental builds beside the product library)
         if not os.path.exists(path):
             raise RtmiError("librtmi.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)")
         L = C.CDLL(path)
