@@ -69,7 +69,7 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 	uint32_t pool_connect; // same for k_trace<any>
 	uint32_t pending;      // paths + carried shadow rays that the next bounce starts with (host loop termination)
 	uint32_t pool_tail;    // next unclaimed entry of the running k_tail round
-	uint32_t tail_mode;    // which kernel the running tail round belongs to (k_tail_decide): 0 k_tail, 1 k_tail_team, 2 k_tail_wave
+	uint32_t tail_mode;    // | TAIL_WAITING: the host waits for the tails (the pinned flag, read once per round); which kernel the running tail round belongs to (k_tail_decide): 0 k_tail, 1 k_tail_team, 2 k_tail_wave
 	uint32_t pad[1];
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
 	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
@@ -78,6 +78,7 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 
 #define FLAG_SPECULAR 1u
 #define FLAG_INSIDE 2u
+#define TAIL_WAITING 0x100u
 #define META_SLOT_MASK 0x01FFFFFFu  // a batch holds at most 2^25 paths
 #define META_AGE_SHIFT 25           // vertices behind the path, saturating at META_AGE_LATE
 #define META_AGE_LATE 15u
@@ -710,8 +711,9 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	// `draining` (pinned host memory): the host has nothing more to enqueue and waits for the tails (rtmi_flush, read-backs):
 	// the chip is this kernel's, so a round (round 0 excepted) spreads its paths over all the waves of the grid, as few to a
 	// wave as that allows: a path's bounce waits for the walks of the others in its wave
-	const bool hurry = dense_above != 0 && *(const volatile uint32_t*)draining != 0;
-	if (team_below && ctr->tail_mode != 0) return; // this round is k_tail_team's or k_tail_wave's (k_tail_decide; launched right after this kernel)
+	const uint32_t mode = ctr->tail_mode; // k_tail_decide's word for this round: the flag is read from host memory once, not by every wave
+	const bool hurry = dense_above != 0 && ( mode & TAIL_WAITING ) != 0;
+	if (team_below && ( mode & 3u ) != 0) return; // this round is k_tail_team's or k_tail_wave's (k_tail_decide; launched right after this kernel)
 	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
 	int per_wave;
@@ -828,7 +830,7 @@ __global__ void k_tail_decide( DevCounters* ctr, const uint32_t* __restrict__ n_
 {
 	const uint32_t n = *n_in;
 	const bool waiting = *(const volatile uint32_t*)draining != 0;
-	ctr->tail_mode = waiting && n <= wave_below ? 2u : waiting && n <= team_below ? 1u : 0u;
+	ctr->tail_mode = ( waiting && n <= wave_below ? 2u : waiting && n <= team_below ? 1u : 0u ) | ( waiting ? TAIL_WAITING : 0u );
 }
 
 // ---- the end of a render: teams of four lanes per path -------------------------------------------------------------------
@@ -845,7 +847,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t n = *n_in;
-	if (ctr->tail_mode != 1) return; // k_tail's or k_tail_wave's round (k_tail_decide)
+	if (( ctr->tail_mode & 3u ) != 1) return; // k_tail's or k_tail_wave's round (k_tail_decide)
 	// teams per wave: as few as the grid allows (a team's bounce waits for the divergence of the other teams of its wave)
 	const uint32_t waves_per_block = blockDim.x >> 6, waves = gridDim.x * waves_per_block;
 	const uint32_t need = ( n + waves - 1 ) / waves;
@@ -1002,7 +1004,7 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 {
 	__shared__ WaveLds lds[WAVE_WG];
 	const uint32_t n = *n_in;
-	if (ctr->tail_mode != 2) return; // another tail kernel's round (k_tail_decide)
+	if (( ctr->tail_mode & 3u ) != 2) return; // another tail kernel's round (k_tail_decide)
 	const int lane = (int)( threadIdx.x & 63u );
 	WaveLds& L = lds[threadIdx.x >> 6];
 	if (( blockIdx.x * (uint32_t)WAVE_WG + ( threadIdx.x >> 6 ) ) >= n) return; // surplus waves leave at once
@@ -1104,7 +1106,15 @@ __global__ __launch_bounds__( 256 ) void k_rays_wave( DScene s, int n, const flo
 // queue that k_primary has just filled, as entries N, N+1, ...: camera-ray paths and carried paths then bounce together.
 // A carried path keeps its slot (it needs it for its pixel only) and its rng state: its arithmetic is what it would have
 // been in a tail of its own.
-__global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32_t* __restrict__ n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap )
+// Veterans: a carried path gets the slot of its pixel in the LAST sample plane a batch can have (k_carry_in; a late path's
+// slot is read modulo W*H only), so a late path whose slot is at or above `veteran_from` when the batch leaves the wavefront
+// loop has already ridden through a batch: it has survived 30+ bounces and is most likely trapped between specular
+// surfaces for hundreds more.  It stays with the batch, whose tail gives it some hundred bounces at once beside the next
+// batches' bulk, instead of 17 per batch as a rider: the fewer such paths are alive when the caller finally waits, the
+// shorter that wait.  (The batch's own paths of that sample plane are taken for veterans too: 1 in S of the newly late
+// paths, a routing matter only.  veteran_from = 0xFFFFFFFF: none.)
+__global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32_t* __restrict__ n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap,
+	uint32_t veteran_from )
 {
 	__shared__ uint32_t lds_a[16], lds_b[16];
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = *n_in;
@@ -1112,7 +1122,7 @@ __global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32
 	uint32_t meta = 0;
 	const bool valid = i < n;
 	if (valid) ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i], meta = in.meta[i];
-	const bool late = valid && ( ( meta >> META_AGE_SHIFT ) & META_AGE_LATE ) == META_AGE_LATE && !( meta & META_SUSPENDED );
+	const bool late = valid && ( ( meta >> META_AGE_SHIFT ) & META_AGE_LATE ) == META_AGE_LATE && !( meta & META_SUSPENDED ) && ( meta & META_SLOT_MASK ) < veteran_from;
 	uint32_t idx[1];
 	{
 		const bool push[1] = { late };
@@ -1128,7 +1138,8 @@ __global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32
 	}
 	if (valid && !carried) rest.o_t[idx[0]] = ot, rest.d_h[idx[0]] = dh, rest.T_s[idx[0]] = ts, rest.meta[idx[0]] = meta;
 }
-__global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, const uint32_t* __restrict__ n_carry, uint32_t cap, PathState st, const uint32_t* __restrict__ n_st, uint32_t* __restrict__ wq, DevCounters* ctr )
+__global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, const uint32_t* __restrict__ n_carry, uint32_t cap, PathState st, const uint32_t* __restrict__ n_st, uint32_t* __restrict__ wq, DevCounters* ctr,
+	uint32_t WH, uint32_t veteran_from )
 {
 	__shared__ uint32_t lds[16];
 	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1143,7 +1154,9 @@ __global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, 
 		st.o_t[N + j] = make_float4( O.x, O.y, O.z, h.t );
 		st.d_h[N + j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
 		st.T_s[N + j] = carry.T_s[j];
-		st.meta[N + j] = carry.meta[j];
+		uint32_t meta = carry.meta[j];
+		if (veteran_from != 0xFFFFFFFFu) meta = ( meta & ~META_SLOT_MASK ) | ( ( meta & META_SLOT_MASK ) % WH + veteran_from ); // (every carried path is late)
+		st.meta[N + j] = meta;
 	}
 	const bool push[1] = { walk };
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
@@ -1599,6 +1612,11 @@ struct rtmi_ctx
 	int hook_kernel = 0;        // option hook_kernel: rtmi_trace_rays runs 0 = k_trace_rays (one ray per lane over the reference's pairs),
 	                            // 1 = the render path's own queues and persistent walk (k_trace: 4-wide nodes where built),
 	                            // 2 = the end-of-render walker, one ray per wave (k_rays_wave = k_tail_wave's device code)
+	// option veteran_rounds: -1 (default) = carried paths are carried again; >= 0: they stay with the batch they rode, whose tail
+	// runs this many extra rounds.  Measured (20 bench steps): the final wait falls from 357 ms to 208 ms (2 rounds) / 190 ms (3),
+	// but the tails' waves beside the bulk cost more than that: 126.4 -> 140.5 ms per step.  A trapped path-bounce costs about
+	// 1 ns as a rider of the wavefront kernels and 2-3 ns in a tail kernel, wherever that tail runs.
+	int veteran_rounds = -1;
 	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
 	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
 	uint32_t team_below = 1u << 17; // option team_below.  Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds):
@@ -1772,7 +1790,7 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		const uint32_t lds_words = (uint32_t)c->walk_depth * 64u * wpb;
 		// a draining round with few paths left belongs to k_tail_team (the device knows the live count and whether the host waits:
 		// both kernels are launched, the one whose round it is not returns at once)
-		if (team_below) hipLaunchKernelGGL( k_tail_decide, dim3( 1 ), dim3( 1 ), 0, ts, ctr, &ctr->n_state[cur], c->draining_dev, team_below, wave_below );
+		hipLaunchKernelGGL( k_tail_decide, dim3( 1 ), dim3( 1 ), 0, ts, ctr, &ctr->n_state[cur], c->draining_dev, team_below, wave_below );
 		if (c->tail_profile)
 			hipLaunchKernelGGL( k_tail<true>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
 				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
@@ -1920,7 +1938,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -1956,6 +1974,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "team_below" )) c->team_below = (uint32_t)v;
 	else if (is( "tail_wave" )) c->tail_wave = v != 0;
 	else if (is( "wave_below" )) c->wave_below = (uint32_t)v;
+	else if (is( "veteran_rounds" )) c->veteran_rounds = (int)v;
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
 	{
@@ -1987,7 +2006,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds;
 	found = false;
 	return 0;
 }
@@ -2570,13 +2589,16 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	if (!last) launch_primary( c, b, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
+	// veterans (k_carry_out): the slots of the last sample plane that fits a batch; needs two planes and the carry
+	const uint32_t planes = (uint32_t)( ( 1ull << 25 ) / (unsigned)WH );
+	const uint32_t veteran_from = c->carry_on && c->veteran_rounds >= 0 && planes >= 2 ? ( planes - 1 ) * (uint32_t)WH : 0xFFFFFFFFu;
 	if (c->carry_on)
 	{
 		// the late paths that earlier batches handed on bounce along with this batch's (entries N, N+1, ...): the carry buffer
 		// (the previous batch's), and what outlived the first tail round of the batch that used this slot before -- of all
 		// slots when this is the last batch
 		auto take = [&]( PathState src, uint32_t* n_src, uint32_t cap ) {
-			hipLaunchKernelGGL( k_carry_in, dim3( ( cap + 511 ) / 512 ), dim3( 512 ), 0, s, c->ds, src, n_src, cap, b.st[0], &ctr->n_state[0], b.wq[0], ctr );
+			hipLaunchKernelGGL( k_carry_in, dim3( ( cap + 511 ) / 512 ), dim3( 512 ), 0, s, c->ds, src, n_src, cap, b.st[0], &ctr->n_state[0], b.wq[0], ctr, (uint32_t)WH, veteran_from );
 			hipLaunchKernelGGL( k_carry_commit, dim3( 1 ), dim3( 1 ), 0, s, &ctr->n_state[0], n_src, cap );
 			upper += cap; };
 		take( c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap );
@@ -2661,7 +2683,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	{
 		// late paths -> carry buffer (they join the next batch, or join_batches finishes them); the others -> the other state set
 		hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, s, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1],
-			c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap );
+			c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap, veteran_from );
 		if (c->log_bounces)
 		{
 			uint32_t rest = 0, carried = 0;
@@ -2685,11 +2707,13 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			// what stays with the batch are the paths that were not late yet (parked walks make a path lag): after the 32 bounces
 			// of the first round the survivors are, and wait in the slot's list for the next batch that uses the slot; only
 			// what does not fit goes through the remaining rounds
-			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 0 );
-			hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, ts, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1], b.left, b.n_left, c->left_cap );
+			// (with veterans: `veteran_rounds` more rounds -- 64, 128, ... bounces -- before the survivors go to the list)
+			const int first_rounds = veteran_from != 0xFFFFFFFFu ? std::min( c->veteran_rounds, 10 ) : 0;
+			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, first_rounds );
+			hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, ts, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1], b.left, b.n_left, c->left_cap, 0xFFFFFFFFu );
 			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 			cur ^= 1;
-			launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), 4096, 1, 11 ); // normally nothing: a small persistent grid
+			launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), 4096, first_rounds + 1, 11 ); // normally nothing: a small persistent grid
 		}
 		else launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 11, last );
 		c->stats.bounce_launches++;

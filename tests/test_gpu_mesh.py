@@ -179,7 +179,8 @@ def test_full_size_image_and_properties(full):
     # the end of a render: the last 16 k paths are walked by teams of four lanes (k_tail_team), the last 4 k by a wave each
     # (k_tail_wave); with both options off they stay with k_tail, one lane per path.  Same (t, leaf position) rule, same
     # arithmetic: same bits.  check_launches synchronises per bounce
-    for opts in (dict(tail_team=0, tail_wave=0, check_launches=1), dict(tail_team=1, tail_wave=0), dict(tail_team=0, tail_wave=1, wave_below=1 << 16)):
+    for opts in (dict(tail_team=0, tail_wave=0, check_launches=1), dict(tail_team=1, tail_wave=0), dict(tail_team=0, tail_wave=1, wave_below=1 << 16),
+                 dict(veteran_rounds=1, batch=1)):  # four batches: the paths carried twice stay with the batch they rode (k_carry_out)
         d4 = api.Device(W, H, **opts)
         d4.upload(scene.desc)
         d4.set_seeds(seeds)
