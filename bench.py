@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--builder", choices=["binned", "reference"], default="binned")
+    ap.add_argument("--zoom", type=float, default=1.0, help="NOT the headline: shrink the screen rectangle about its centre (a view filled by the middle knot)")
+    ap.add_argument("--tube", type=float, default=0.075, help="NOT the headline: tube radius of the knots (0.075 in every config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
@@ -114,12 +116,15 @@ def main():
 
     W, H = a.width, a.height
     t0 = time.time()
-    scene = api.mesh_scene(a.tris, api.BINNED_SAH if a.builder == "binned" else api.REFERENCE_SAH)
+    scene = api.mesh_scene(a.tris, api.BINNED_SAH if a.builder == "binned" else api.REFERENCE_SAH, tube=a.tube)
     info = scene.info()
     build_s = time.time() - t0
     dev = api.Device(W, H, local_rank)
     dev.upload(scene.desc)
-    dev.set_camera(api.default_camera(W, H, scene.scale))
+    dev.set_camera(api.zoom_camera(api.default_camera(W, H, scene.scale), a.zoom))
+    # how much of the view is mesh: camera rays whose nearest hit is a triangle (the analytic primitives come first in the numbering)
+    n_analytic = info["quads"] + info["spheres"] + info["cubes"] + info["planes"]
+    primary_mesh_fraction = float((dev.trace_primary()[0] >= n_analytic).mean())
     seeds = api.seed_table(W * H)
     dev.set_seeds(seeds)
     # Everything below runs on ONE explicit torch stream: the library enqueues on it (rtmi_set_stream takes the stream as it
@@ -208,6 +213,8 @@ def main():
         walk_s = st["ms_walk"] * 1e-3
         pair_achieved = (ext_bytes + any_bytes) / walk_s / 1e9 if walk_s > 0 else None
         cfg = "configs[3]" if strong and (W, H) == (3840, 2160) else "configs[2]"
+        if a.zoom != 1.0 or a.tube != 0.075:
+            cfg = "NOT a config of BASELINE.json (mesh-dominated view for the walk kernels: zoom %g, tube radius %g)" % (a.zoom, a.tube)
         per = ("one frame of %d spp per step split over the ranks" % a.total_spp) if strong else ("%d spp per step per GPU" % spp)
         out = {
             "metric": "Mrays/s (whole node), path-traced OBJ scene 1080p", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
@@ -223,7 +230,7 @@ def main():
             "extend_walkers": float(st["extend_walkers"]), "shadow_walkers": float(st["shadow_walkers"]), "rays_per_path": total_rays / max(1.0, paths),
             # what the headline counts: every closest-hit and any-hit ray.  Most of them end on the room's analytic primitives inside
             # the kernel that created them; the rays that enter the BVH's root box and walk the tree (rank 0's counters):
-            "walked_mrays_per_s": walked / dt / 1e6,
+            "walked_mrays_per_s": walked / dt / 1e6, "primary_mesh_fraction": primary_mesh_fraction,
             "extend_walk_fraction": float(st["extend_walkers"]) / max(1.0, float(st["extend_rays"])),
             "shadow_walk_fraction": float(st["shadow_walkers"]) / max(1.0, float(st["shadow_rays"])),
             # host time from rtmi_flush to the return of rtmi_finalize: the last paths of the render (+ reduce and finalize)

@@ -312,7 +312,7 @@ def mesh_scale(n_tris_target, target_area=4e-4):
     return float(max(1, int(np.ceil((n_tris_target * target_area / area1) ** 0.5))))
 
 
-def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None, scale=None):
+def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None, scale=None, tube=0.075):
     """The mesh configs of SURVEY 8d: the reference room (6 planes + light quad) with three torus knots at
     x = -1.5, 0, +1.5, z = 1.5 (the monkeys' places, scene.h:80-82): diffuse red, mirror, glass n=1.52, everything
     multiplied by mesh_scale(n) (see there; use default_camera(w, h, scene.scale) with it).  n_tris_target is the
@@ -325,7 +325,7 @@ def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None, scale=None):
     nu = max(8, int(round(n_tris_target / 6.0 / nv)))
     mats = materials or [Material(DIFFUSE, (0.93, 0.21, 0.21)), Material(MIRROR, (0.93, 0.93, 0.93)), Material(GLASS, (0.93, 0.93, 0.93), 1.52)]
     for m, x in zip(mats, (-1.5, 0.0, 1.5)):
-        s.add_torus_knot(nu, nv, (x * k, 0.0, 1.5 * k), m, 0.42 * k, 0.17 * k, 0.075 * k)
+        s.add_torus_knot(nu, nv, (x * k, 0.0, 1.5 * k), m, 0.42 * k, 0.17 * k, tube * k)  # (tube: 0.075 in every config; thicker for the mesh-dominated profile view)
     return s.finalize(builder)
 
 
@@ -340,6 +340,16 @@ def default_camera(w, h, scale=1.0):
     cam = np.zeros(16, np.float32)
     host_lib().rth_camera_default(w, h, _ptr(cam))
     return cam * np.float32(scale)
+
+
+def zoom_camera(cam16, zoom):
+    """The same eye, the screen rectangle shrunk about its centre by `zoom` (< 1: a narrower field of view)."""
+    cam = np.array(cam16, np.float32).reshape(4, 4).copy()
+    tl, tr, bl = cam[1, :3].copy(), cam[2, :3].copy(), cam[3, :3].copy()
+    centre = (tr + bl) * np.float32(0.5)
+    for i, c in ((1, tl), (2, tr), (3, bl)):
+        cam[i, :3] = centre + (c - centre) * np.float32(zoom)
+    return cam.reshape(16)
 
 
 class Device:

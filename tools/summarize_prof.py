@@ -8,7 +8,7 @@ import re
 import sys
 from collections import defaultdict
 
-KERNELS = ("k_primary", "k_trace_rays", "k_trace", "k_tail", "k_shade", "k_accumulate", "k_finalize", "k_whitted", "k_next_bounce", "k_copy_hits",
+KERNELS = ("k_primary", "k_trace_rays", "k_trace", "k_tail_team", "k_tail_wave", "k_tail_decide", "k_tail", "k_carry_in", "k_carry_out", "k_fold_late", "k_shade", "k_accumulate", "k_finalize", "k_whitted", "k_next_bounce", "k_copy_hits",
            "k_gamma", "k_chroma", "k_vignette")
 
 
@@ -23,7 +23,7 @@ def short(name):
     return n[:60]
 
 
-def main(out):
+def main(out, command="bench.py --steps 3 --warmup 1"):
     files = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     per = defaultdict(list)
@@ -35,7 +35,7 @@ def main(out):
             a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
             per[k].append((d, r.get("Grid_Size", "?"), r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?")))
     total = sum(a[1] for a in agg.values()) or 1
-    print("== kernel trace (rocprofv3 --kernel-trace --stats), bench.py --steps 3 --warmup 1 (incl. counting pass + warmup) ==")
+    print("== kernel trace (rocprofv3 --kernel-trace --stats) of `%s` (incl. counting pass + warmup) ==" % command)
     print("%-28s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-28s %8d %12.1f %10.2f %10.2f %10.1f %6.1f" % (k, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / total))
@@ -76,4 +76,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

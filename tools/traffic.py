@@ -23,11 +23,15 @@ def sums(d, sub, counter):
 
 
 d, out = sys.argv[1], sys.argv[2]
+command = sys.argv[3] if len(sys.argv) > 3 else "bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 fetch, write = sums(d, "pmc_fetch", "FETCH_SIZE"), sums(d, "pmc_write", "WRITE_SIZE")
-res = {"source": os.path.basename(d.rstrip("/")), "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline (tools/profile_gpu.sh)", "unit": "bytes per launch",
+hit, miss = sums(d, "pmc_write", "TCC_HIT_sum"), sums(d, "pmc_write", "TCC_MISS_sum")
+res = {"source": os.path.basename(d.rstrip("/")), "command": command, "unit": "bytes per launch",
        "correction": "2 x FETCH_SIZE (gfx950, 16-B/lane loads) + WRITE_SIZE, KiB -> bytes", "kernels": {}}
 for k in fetch:
     f, nf = fetch[k]; w, nw = write.get(k, (0.0, nf))
-    res["kernels"][k] = {"launches": nf, "fetch_kib_raw": f, "write_kib_raw": w, "traffic_bytes_per_launch": (2 * f / nf + w / max(nw, 1)) * 1024}
+    res["kernels"][k] = {"launches": nf, "fetch_kib_raw": f, "write_kib_raw": w, "traffic_bytes_per_launch": (2 * f / nf + w / max(nw, 1)) * 1024, "command": command}
+    if k in hit and k in miss and hit[k][0] + miss[k][0] > 0:  # L2 (TCC) requests served by the L2 itself, over all of the kernel's launches
+        res["kernels"][k]["l2_hit_rate"] = hit[k][0] / (hit[k][0] + miss[k][0])
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["kernels"], indent=1))
