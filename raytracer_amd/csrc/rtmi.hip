@@ -1592,6 +1592,8 @@ struct rtmi_ctx
 	DevCounters* carry_ctr = 0;  // n_state[0] = paths in carry[0]
 	uint32_t carry_cap = 1u << 23, left_cap = 1u << 16;
 	bool carry_on = true;        // RTMI_CARRY=0: every batch finishes all of its paths in its own tail
+	bool paths_carried = false;  // some batch since the last join handed paths on (carry buffer, slot lists): the next batch, or join_batches, takes them in
+	uint32_t carry_min = 1u << 22; // option carry_min: a batch of no more camera paths than this finishes its own paths (see render_batch)
 	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
 	uint32_t small_paths = 1u << 18; // a batch with no more paths than this leaves the wavefront loop at once
 	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
@@ -1843,12 +1845,13 @@ static int join_batches( rtmi_ctx* c )
 	{
 		// The late paths that the last batch handed on have no batch to ride with: they get a batch of their own, without
 		// camera rays (S = 0): wavefront bounces while they are many, then k_tail.
-		if (c->carry_on)
+		if (c->carry_on && c->paths_carried)
 		{
 			BatchSlot& b = c->slots[c->next_slot];
 			c->next_slot = ( c->next_slot + 1 ) % c->n_slots;
 			int r = render_batch( c, b, 0, 0, 1 );
 			if (r) return r;
+			c->paths_carried = false;
 		}
 		if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
 		// fold the late sums of all batches since the last read into the accumulator
@@ -1938,7 +1941,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -1975,6 +1978,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "tail_wave" )) c->tail_wave = v != 0;
 	else if (is( "wave_below" )) c->wave_below = (uint32_t)v;
 	else if (is( "veteran_rounds" )) c->veteran_rounds = (int)v;
+	else if (is( "carry_min" )) c->carry_min = (uint32_t)v;
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
 	{
@@ -2006,7 +2010,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min;
 	found = false;
 	return 0;
 }
@@ -2585,14 +2589,19 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	DevCounters* ctr = b.ctr;
 	if (b.busy) { HIPCHK( hipStreamWaitEvent( s, b.acc_done, 0 ) ); b.busy = false; } // the slot's previous batch is done with these buffers
 	HIPCHK( hipMemsetAsync( ctr, 0, 64, s ) ); // queue lengths and pools
-	const bool last = S == 0; // the batch of the carried paths alone (join_batches): nothing is handed on
-	if (!last) launch_primary( c, b, N, sample_begin, stride );
+	// `last`: nothing is handed on.  The batch of the carried paths alone (join_batches, S = 0) -- and a SMALL batch: handing late
+	// paths on keeps the bounces of a 33 M-path batch large; a batch that starts below the hand-over size (one sample of a 720p
+	// frame: Renderer::Tick) would only move its paths from one small launch to another, and when the caller reads right after it
+	// (Tick does) they would get a second batch of their own.  It finishes its paths itself: wavefront bounces down to
+	// small_paths, then the tail rounds, which run for latency if the host is already waiting when they start (k_tail_decide).
+	const bool last = S == 0 || N <= c->carry_min;
+	if (S != 0) launch_primary( c, b, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
 	// veterans (k_carry_out): the slots of the last sample plane that fits a batch; needs two planes and the carry
 	const uint32_t planes = (uint32_t)( ( 1ull << 25 ) / (unsigned)WH );
 	const uint32_t veteran_from = c->carry_on && c->veteran_rounds >= 0 && planes >= 2 ? ( planes - 1 ) * (uint32_t)WH : 0xFFFFFFFFu;
-	if (c->carry_on)
+	if (c->carry_on && c->paths_carried)
 	{
 		// the late paths that earlier batches handed on bounce along with this batch's (entries N, N+1, ...): the carry buffer
 		// (the previous batch's), and what outlived the first tail round of the batch that used this slot before -- of all
@@ -2605,7 +2614,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		for (int k = 0; k < c->n_slots; k++)
 		{
 			BatchSlot& o = c->slots[k];
-			if (&o != &b && !last) continue;
+			if (&o != &b && S != 0) continue;
 			if (&o != &b && o.busy) { HIPCHK( hipStreamWaitEvent( s, o.acc_done, 0 ) ); o.busy = false; } // its tail stream has written its list
 			take( o.left, o.n_left, c->left_cap );
 		}
@@ -2681,6 +2690,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	close_window();
 	if (tail && c->carry_on && !last)
 	{
+		c->paths_carried = true;
 		// late paths -> carry buffer (they join the next batch, or join_batches finishes them); the others -> the other state set
 		hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, s, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1],
 			c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap, veteran_from );
@@ -2719,7 +2729,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		c->stats.bounce_launches++;
 	}
 	if (c->last_acc) HIPCHK( hipStreamWaitEvent( ts, c->last_acc, 0 ) ); // accumulate in batch order
-	if (!last)
+	if (S != 0)
 	{
 		ScopedTimer t( c, 3, ts );
 		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, ts, c->accum, b.E, b.Es, WH, S );

@@ -124,7 +124,8 @@ def test_full_size_image_and_properties(full):
     d.reset()
     d.render(api.PATHTRACING, 0, 1, 1)
     assert np.array_equal(bits(d.accumulator()), bits(one))
-    # batching: 4 samples in one batch == 4 batches of one sample (accumulation is in sample order either way)
+    # batching: 4 samples in one batch == 4 batches of one sample (accumulation is in sample order either way; the batch of 8 M
+    # paths hands its late paths on, a batch of 2 M is below option carry_min and finishes its own: same bits)
     d.reset()
     d.render(api.PATHTRACING, 0, 4, 1)
     four = d.accumulator()
@@ -180,7 +181,8 @@ def test_full_size_image_and_properties(full):
     # (k_tail_wave); with both options off they stay with k_tail, one lane per path.  Same (t, leaf position) rule, same
     # arithmetic: same bits.  check_launches synchronises per bounce
     for opts in (dict(tail_team=0, tail_wave=0, check_launches=1), dict(tail_team=1, tail_wave=0), dict(tail_team=0, tail_wave=1, wave_below=1 << 16),
-                 dict(veteran_rounds=1, batch=1)):  # four batches: the paths carried twice stay with the batch they rode (k_carry_out)
+                 dict(batch=1, carry_min=0),  # four batches that hand their late paths on, although each is small enough to finish its own (carry_min)
+                 dict(veteran_rounds=1, batch=1, carry_min=0)):  # ... and the paths carried twice stay with the batch they rode (k_carry_out)
         d4 = api.Device(W, H, **opts)
         d4.upload(scene.desc)
         d4.set_seeds(seeds)
