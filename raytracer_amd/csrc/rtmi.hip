@@ -2771,10 +2771,13 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 	if (mode == RTMI_PATHTRACING)
 	{
 		if (sample_count <= 0 || sample_stride <= 0 || sample_begin < 0) return fail( c, RTMI_ERR_INVALID, "bad sample range" );
-		*(volatile uint32_t*)c->draining = 0; // more bulk work is coming: the tails in flight run for throughput again
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
 		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
 		if (c->batch_opt > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, c->batch_opt ), ( 1ll << 25 ) / WH ) );
+		// more bulk work is coming: the tails in flight run for throughput again.  Not so for a call of one small batch (a frame of
+		// the interactive loop): there is no bulk for its tail to run beside, and the read that follows finds the host still
+		// enqueuing when the first tail rounds decide (k_tail_decide) -- they run for latency from the start
+		*(volatile uint32_t*)c->draining = sample_count <= S && (unsigned long long)S * WH <= c->carry_min ? 1u : 0u;
 		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
 		for (int k = 0; k < c->n_slots; k++) { int r = ensure_batch( c, c->slots[k], S ); if (r) return r; }
 		for (int done = 0; done < sample_count; done += S)
