@@ -182,9 +182,11 @@ int rtmi_synchronize( rtmi_ctx* );
  * in flight: paths that are alive after many bounces travel on with the next render batches, and what they contribute
  * is kept in exact per-pixel sums beside the accumulator.  Every rtmi_* call that reads or resets the accumulator first
  * finishes those paths, adds the sums to the accumulator and orders itself after all of it; a caller that consumes a
- * caller-owned accumulator (rtmi_set_accumulator) on its own stream calls rtmi_flush first: non-blocking for the host,
- * it enqueues that completion and makes the handle's stream wait for everything rendered so far.  The accumulator is
- * the sum of whole samples only after one of these calls. */
+ * caller-owned accumulator (rtmi_set_accumulator) on its own stream calls rtmi_flush first: it enqueues that completion
+ * and makes the handle's stream wait for everything rendered so far, without waiting for it on the host -- except that,
+ * when earlier batches handed paths on, those paths' first wavefront bounces are paced by the host like any batch's (it
+ * reads each bounce's path count two bounces late: a few ms); the long part, the tail rounds, is only enqueued.  The
+ * accumulator is the sum of whole samples only after one of these calls. */
 int rtmi_flush( rtmi_ctx* );
 /* Multi-GPU inside the boundary (no reference counterpart: it has one OpenCL context, precomp.h:1544-1546).  Samples are
  * split by index over one handle per GPU (rtmi_render's sample_begin / sample_stride); this sums the float4[W*H]
