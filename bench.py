@@ -34,12 +34,6 @@ import os
 import sys
 import time
 
-# librtmi uses six HIP streams (the caller's, a side stream for the shadow walks, four for the batch tails).  With HIP's
-# default of 4 hardware queues two of them share a queue and a shadow walk can sit behind a tail round: 8 queues keep them
-# apart (+2 % rays/s; the value must be in the environment before the HIP runtime starts, i.e. before torch is imported).
-if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
-
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -58,6 +52,9 @@ def parse():
     ap.add_argument("--builder", choices=["binned", "reference"], default="binned")
     ap.add_argument("--zoom", type=float, default=1.0, help="NOT the headline: shrink the screen rectangle about its centre (a view filled by the middle knot)")
     ap.add_argument("--tube", type=float, default=0.075, help="NOT the headline: tube radius of the knots (0.075 in every config)")
+    ap.add_argument("--hw-queues", type=int, default=16,
+                    help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4; 0 = leave the environment alone).  With 12 or more the library "
+                         "renders on two lanes (two batches in flight side by side, option lanes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
@@ -90,6 +87,10 @@ def committed_pmc():
 
 def main():
     a = parse()
+    # hardware queues: the library's streams (per lane: main, side, four tails) must not share them; the HIP runtime reads this
+    # when it starts, i.e. at the first import of torch below
+    if a.hw_queues > 0 and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < a.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(a.hw_queues, 32))
     pmc, pmc_file = committed_pmc()
     traffic_source = "--traffic-bytes-per-launch" if a.traffic_bytes_per_launch is not None else None
     if a.traffic_bytes_per_launch is None and "traffic_bytes_per_launch" in pmc:
@@ -215,9 +216,14 @@ def main():
     if rank == 0:
         bytes_per_extend_ray = 64.0 * pairs_per_ray + 48.0 * prims_per_ray + 44.0  # per ray that walks the BVH
         ext_bytes = st["extend_walkers"] * bytes_per_extend_ray
-        ext_s = st["ms_extend"] * 1e-3
+        # time during which the kernel was running: with one lane the sum of its launches; with two lanes two launches, one per lane,
+        # run side by side and each one's own duration includes the time it shared the chip with the other, so the bytes of all
+        # launches are divided by the UNION of their intervals (rtmi_stats.ms_extend_union; equal to the sum for one lane)
+        lanes = dev.get_option("lanes")
+        ext_s = (st["ms_extend_union"] if st["ms_extend_union"] > 0 else st["ms_extend"]) * 1e-3
         n_launch = max(1, st["n_extend_launches"])
         achieved = ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
+        per_launch = ext_bytes / (st["ms_extend"] * 1e-3) / 1e9 if st["ms_extend"] > 0 else 0.0
         peak = 8000.0
         # a bounce's shadow walk shares the chip with the next bounce's closest-hit walk: each launch's
         # event-timed duration includes the other's share.  Both walks over the windows they share (shade to shade):
@@ -237,7 +243,7 @@ def main():
                                    % (cfg, scene.scale, info["triangles"], W, H, per, "per step (every step is a delivered frame)" if strong else "at the end"), "scene_scale": scene.scale,
                        "triangles": info["triangles"], "bvh_nodes": info["nodes_used"], "bvh_depth": info["max_depth"], "builder": a.builder,
                        "width": W, "height": H, "spp_per_step": step_spp // v_world, "total_spp": a.steps * step_spp, "parallelism": "sample-split x%d" % world,
-                       "reduce": a.reduce},
+                       "reduce": a.reduce, "lanes_per_gpu": lanes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays,
             "extend_walkers": float(st["extend_walkers"]), "shadow_walkers": float(st["shadow_walkers"]), "rays_per_path": total_rays / max(1.0, paths),
             # what the headline counts: every closest-hit and any-hit ray.  Most of them end on the room's analytic primitives inside
@@ -251,6 +257,9 @@ def main():
             "scene_build_s": build_s,
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": a.traffic_bytes_per_launch, "traffic_source": traffic_source, "bytes_per_launch": ext_bytes / n_launch, "avg_launch_ms": st["ms_extend"] / n_launch,
+                         "lanes": lanes, "kernel_running_ms": ext_s * 1e3, "sum_of_launch_ms": st["ms_extend"],
+                         "per_launch": {"note": "bytes per launch / mean launch duration; with two lanes a launch shares the chip with the other lane's launch of the same kernel",
+                                        "achieved": per_launch, "frac": per_launch / peak},
                          "launches": st["n_extend_launches"], "bytes_per_walked_ray": bytes_per_extend_ray, "node_pairs_per_walked_ray": pairs_per_ray,
                          "leaf_prims_per_walked_ray": prims_per_ray, "shadow_node_pairs_per_walked_ray": spairs_per_ray,
                          "shadow_leaf_prims_per_walked_ray": sprims_per_ray, "longest_walk_steps": [cs["max_extend_steps"], cs["max_shadow_steps"]],

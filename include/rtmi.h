@@ -111,6 +111,9 @@ typedef struct rtmi_stats {
 	uint64_t tail_profile[12];
 	double   ms_drain;          /* host time spent inside the read-back / flush calls waiting for the last paths (always measured) */
 	uint64_t n_drains;
+	double   ms_extend_union;   /* profiling mode: time during which at least one closest-hit walk launch was running.  With one lane
+	                               it equals ms_extend; with option lanes = 2 two launches (one per lane) overlap and each one's
+	                               own duration includes the time it shared the chip with the other */
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,

@@ -35,6 +35,8 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <thread>
+#include <condition_variable>
 #include <dlfcn.h>
 #include <chrono>
 
@@ -1559,9 +1561,39 @@ struct BatchSlot
 	bool busy = false;          // acc_done has been recorded and not yet waited for by a new user of the slot
 };
 
+// The accumulator sums the batches in sample order (renderer.cpp:566-567), whichever lane (below) renders them: every batch
+// draws a ticket when it is dispatched and takes its turn at the point where it enqueues its k_accumulate -- wait for the
+// previous batch's event, launch, record its own.  Two host threads at most; a batch that fails still passes its turn on.
+struct AccChain
+{
+	std::mutex m;
+	std::condition_variable cv;
+	uint64_t next_ticket = 0, turn = 0;
+	hipEvent_t last_acc = 0; // acc_done of the most recent batch: the next accumulate and every reader wait for it
+};
+struct Turn
+{
+	AccChain* ch; uint64_t ticket; bool entered = false, left = false;
+	std::unique_lock<std::mutex> lk;
+	Turn( AccChain* ch, uint64_t ticket ) : ch( ch ), ticket( ticket ), lk( ch->m, std::defer_lock ) {}
+	void enter() { if (entered) return; lk.lock(); ch->cv.wait( lk, [&] { return ch->turn == ticket; } ); entered = true; }
+	void leave() { if (left) return; enter(); ch->turn++; left = true; lk.unlock(); ch->cv.notify_all(); }
+	~Turn() { leave(); }
+};
+
 struct rtmi_ctx
 {
 	int device = 0, W = 0, H = 0;
+	// Second lane (option lanes = 2): a whole second pipeline -- streams, batch slots, carry buffer -- in a context of its own that
+	// shares this one's scene, seeds, accumulator and late sums.  rtmi_render gives every other batch to it, enqueued by a second
+	// host thread, so that two full batches are in flight: one's k_shade and small late bounces run beside the other's walks.
+	rtmi_ctx* child = 0;
+	bool is_child = false;
+	int lanes = 1;
+	uint32_t* child_seeds = 0; long long* child_late = 0; float4* child_odd = 0; // the child's own allocations (it uses the parent's while it lives)
+	hipEvent_t ev_fork = 0, ev_join = 0;
+	uint64_t batch_seq = 0;      // batches dispatched: even ones run here, odd ones on the child
+	AccChain own_chain; AccChain* chain = &own_chain;
 	hipStream_t own_stream = 0, stream = 0;
 	std::string err;
 	bool has_scene = false;
@@ -1597,7 +1629,6 @@ struct rtmi_ctx
 	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
 	uint32_t small_paths = 1u << 18; // a batch with no more paths than this leaves the wavefront loop at once
 	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
-	hipEvent_t last_acc = 0;     // acc_done of the most recent batch: the next accumulate and every reader wait for it
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
 	int sblock = 512;            // threads per block of k_primary / k_shade (RTMI_SBLOCK): blocks of 16 waves wait for a CU with 4 free
@@ -1638,6 +1669,8 @@ struct rtmi_ctx
 	struct TimedEv { hipEvent_t a, b; int cls; };
 	std::vector<TimedEv> timed;
 	std::vector<hipEvent_t> ev_pool;
+	hipEvent_t prof_base = 0;    // recorded when event timing is switched on: launch intervals are taken relative to it
+	std::vector<std::pair<float, float>> ext_intervals; // [start, end) of the closest-hit walk launches since rtmi_reset_stats, ms after prof_base
 };
 
 // ---- rtmi_trace_rays_noalloc: staging in a file-scope device array instead of allocated memory --------------------------
@@ -1720,7 +1753,12 @@ static void resolve_timers( rtmi_ctx* c )
 		float ms = 0;
 		if (hipEventSynchronize( t.b ) == hipSuccess && hipEventElapsedTime( &ms, t.a, t.b ) == hipSuccess)
 		{
-			if (t.cls == 0) c->stats.ms_extend += ms, c->stats.n_extend_launches++;
+			if (t.cls == 0)
+			{
+				c->stats.ms_extend += ms, c->stats.n_extend_launches++;
+				float t0 = 0;
+				if (c->prof_base && hipEventElapsedTime( &t0, c->prof_base, t.a ) == hipSuccess) c->ext_intervals.push_back( { t0, t0 + ms } );
+			}
 			else if (t.cls == 1) c->stats.ms_shade += ms, c->stats.n_shade_launches++;
 			else if (t.cls == 2) c->stats.ms_connect += ms, c->stats.n_connect_launches++;
 			else if (t.cls == 4) c->stats.ms_walk += ms, c->stats.n_walk_windows++;
@@ -1831,37 +1869,53 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 	return cur;
 }
 
-static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride );
+static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride, uint64_t ticket );
 
 static double now_ms() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 // host time from the call that starts finishing the paths in flight to the return of the blocking call that needed them
 static void drain_closed( rtmi_ctx* c ) { if (c->drain_open) c->stats.ms_drain += now_ms() - c->drain_t0, c->stats.n_drains++, c->drain_open = false; }
 
+// the camera-less batch of a lane whose batches handed paths on (see join_batches)
+static int join_lane( rtmi_ctx* c, uint64_t ticket )
+{
+	(void)hipSetDevice( c->device );
+	BatchSlot& b = c->slots[c->next_slot];
+	c->next_slot = ( c->next_slot + 1 ) % c->n_slots;
+	int r = render_batch( c, b, 0, 0, 1, ticket );
+	if (!r) c->paths_carried = false;
+	return r;
+}
 static int join_batches( rtmi_ctx* c )
 {
+	rtmi_ctx* k = c->child;
 	if (c->draining) *(volatile uint32_t*)c->draining = 1; // the caller is about to wait for the tails
-	if (c->carry_pending && !c->drain_open) c->drain_open = true, c->drain_t0 = now_ms();
-	if (c->carry_pending && c->has_scene && c->slots[c->next_slot].E)
+	if (k && k->draining) *(volatile uint32_t*)k->draining = 1;
+	const bool pending = c->carry_pending || ( k && k->carry_pending );
+	if (pending && !c->drain_open) c->drain_open = true, c->drain_t0 = now_ms();
+	if (pending && c->has_scene)
 	{
-		// The late paths that the last batch handed on have no batch to ride with: they get a batch of their own, without
-		// camera rays (S = 0): wavefront bounces while they are many, then k_tail.
-		if (c->carry_on && c->paths_carried)
-		{
-			BatchSlot& b = c->slots[c->next_slot];
-			c->next_slot = ( c->next_slot + 1 ) % c->n_slots;
-			int r = render_batch( c, b, 0, 0, 1 );
-			if (r) return r;
-			c->paths_carried = false;
-		}
-		if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
+		// The late paths that the last batches handed on have no batch to ride with: they get a batch of their own, without
+		// camera rays (S = 0): wavefront bounces while they are many, then k_tail.  One per lane, enqueued side by side.
+		const bool mine = c->carry_on && c->paths_carried && c->slots[c->next_slot].E, kids = k && k->carry_on && k->paths_carried && k->slots[k->next_slot].E;
+		int rk = RTMI_OK, r = RTMI_OK;
+		uint64_t t0;
+		{ std::lock_guard<std::mutex> lock( c->chain->m ); t0 = c->chain->next_ticket; c->chain->next_ticket += ( mine ? 1 : 0 ) + ( kids ? 1 : 0 ); }
+		std::thread th;
+		if (kids) th = std::thread( [&] { rk = join_lane( k, t0 ); } );
+		if (mine) r = join_lane( c, t0 + ( kids ? 1 : 0 ) );
+		if (th.joinable()) th.join();
+		if (rk) { c->err = k->err; return rk; }
+		if (r) return r;
+		if (c->chain->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->chain->last_acc, 0 ) );
 		// fold the late sums of all batches since the last read into the accumulator
 		ScopedTimer t( c, 3, c->stream );
 		hipLaunchKernelGGL( k_fold_late, dim3( nblocks( (size_t)c->W * c->H ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->late, c->odd, c->W * c->H );
 		HIPCHK( hipGetLastError() );
 		c->carry_pending = false;
+		if (k) k->carry_pending = false;
 		return RTMI_OK;
 	}
-	if (c->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->last_acc, 0 ) );
+	if (c->chain->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->chain->last_acc, 0 ) );
 	return RTMI_OK;
 }
 
@@ -1871,8 +1925,8 @@ static int sync_all( rtmi_ctx* c )
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	if (c->side) HIPCHK( hipStreamSynchronize( c->side ) );
 	for (int k = 0; k < MAX_SLOTS; k++) if (c->slots[k].tail_stream) { HIPCHK( hipStreamSynchronize( c->slots[k].tail_stream ) ); c->slots[k].busy = false; }
-	c->last_acc = 0;
-	drain_closed( c );
+	if (c->child) { int r = sync_all( c->child ); if (r) { c->err = c->child->err; return r; } }
+	if (!c->is_child) c->chain->last_acc = 0, drain_closed( c );
 	return RTMI_OK;
 }
 
@@ -1934,6 +1988,7 @@ static void set_max_blocks( rtmi_ctx* c )
 	c->max_blocks = c->n_cus * per_cu;
 }
 
+static int set_lanes( rtmi_ctx* c );
 struct OptDesc { const char* key; long long lo, hi; };
 static const OptDesc g_opts[] = {
 	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "carry", 0, 1 }, { "tail_lanes", 1, 64 }, { "tail_waves", 1, 32 }, { "sblock", 256, 1024 },
@@ -1941,7 +1996,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 }, { "lanes", 1, 2 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -1979,6 +2034,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "wave_below" )) c->wave_below = (uint32_t)v;
 	else if (is( "veteran_rounds" )) c->veteran_rounds = (int)v;
 	else if (is( "carry_min" )) c->carry_min = (uint32_t)v;
+	else if (is( "lanes" )) { c->lanes = (int)v; if (live) { int r = set_lanes( c ); if (r) return r; } }
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
 	{
@@ -1991,6 +2047,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 		if (live)
 		{
 			free_batches( c ); // the queues of a batch are sized for the paths carried in
+			if (c->child) free_batches( c->child ); // (its capacities follow at its next use: sync_child)
 			int r = is( "carry_cap" ) ? alloc_carry( c ) : RTMI_OK;
 			if (!r && is( "left_cap" )) for (auto& b : c->slots) if (b.ctr && !r) r = alloc_left( c, b );
 			if (r) return r;
@@ -2010,9 +2067,67 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes;
 	found = false;
 	return 0;
+}
+
+// ---- the second lane -----------------------------------------------------------------------------------------------------
+// Everything a batch reads from its context, copied from the parent before the child is used (the caller may have changed
+// options, camera, scene or accumulator since); buffers that the options size are re-made when the sizes differ.
+static int sync_child( rtmi_ctx* c )
+{
+	rtmi_ctx* k = c->child;
+	if (!k) return RTMI_OK;
+	k->ds = c->ds, k->has_scene = c->has_scene, k->stack_depth = c->stack_depth, k->walk_depth = c->walk_depth;
+	k->overlap_on = c->overlap_on && k->side != 0, k->wide_on = c->wide_on, k->refill = c->refill, k->max_blocks = c->max_blocks;
+	for (int i = 0; i < 2; i++) k->grid_closest[i] = c->grid_closest[i], k->grid_any[i] = c->grid_any[i];
+	k->cam = c->cam, k->seeds = c->seeds, k->accum = c->accum, k->late = c->late, k->odd = c->odd;
+	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
+	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense, k->tail_mid = c->tail_mid;
+	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
+	k->veteran_rounds = c->veteran_rounds, k->tail_team = c->tail_team, k->tail_profile = c->tail_profile, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
+	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base;
+	int r = RTMI_OK;
+	if (k->carry_cap != c->carry_cap) { r = apply_option( k, "carry_cap", c->carry_cap, true ); if (r) return r; }
+	if (k->left_cap != c->left_cap) { r = apply_option( k, "left_cap", c->left_cap, true ); if (r) return r; }
+	if (k->n_slots != c->n_slots) { r = apply_option( k, "slots", c->n_slots, true ); if (r) return r; }
+	return RTMI_OK;
+}
+// lanes = 2: make the child; lanes = 1: retire it.  The caller has joined and synchronised.
+static int set_lanes( rtmi_ctx* c )
+{
+	if (c->is_child) return RTMI_OK;
+	if (c->lanes >= 2 && !c->child)
+	{
+		rtmi_ctx* k = 0;
+		int r = rtmi_create( &k, c->device, c->W, c->H );
+		if (r) return fail( c, r, "option lanes: the second lane could not be created" );
+		k->is_child = true, k->lanes = 1, k->chain = c->chain;
+		k->child_seeds = k->seeds, k->child_late = k->late, k->child_odd = k->odd; // its own, unused while it shares the parent's
+		c->child = k;
+		if (!c->ev_fork && ( hipEventCreateWithFlags( &c->ev_fork, hipEventDisableTiming ) != hipSuccess || hipEventCreateWithFlags( &c->ev_join, hipEventDisableTiming ) != hipSuccess ))
+			return fail( c, RTMI_ERR_HIP, "hipEventCreate" );
+	}
+	else if (c->lanes < 2 && c->child)
+	{
+		rtmi_ctx* k = c->child;
+		k->seeds = k->child_seeds, k->late = k->child_late, k->odd = k->child_odd, k->accum = k->accum_own, k->ds = DScene{}, k->has_scene = false;
+		c->child = 0;
+		rtmi_destroy( k );
+	}
+	return RTMI_OK;
+}
+static void merge_stats( rtmi_stats& a, rtmi_stats& b ) // a += b, b = 0
+{
+	a.primary_samples += b.primary_samples, a.extend_rays += b.extend_rays, a.shadow_rays += b.shadow_rays, a.extend_pairs += b.extend_pairs, a.extend_prims += b.extend_prims;
+	a.shadow_pairs += b.shadow_pairs, a.shadow_prims += b.shadow_prims, a.bounce_launches += b.bounce_launches;
+	a.ms_extend += b.ms_extend, a.ms_shade += b.ms_shade, a.ms_connect += b.ms_connect, a.ms_other += b.ms_other, a.ms_walk += b.ms_walk;
+	a.n_extend_launches += b.n_extend_launches, a.n_shade_launches += b.n_shade_launches, a.n_connect_launches += b.n_connect_launches, a.n_walk_windows += b.n_walk_windows;
+	a.extend_walkers += b.extend_walkers, a.shadow_walkers += b.shadow_walkers, a.suspended += b.suspended;
+	a.max_extend_steps = std::max( a.max_extend_steps, b.max_extend_steps ), a.max_shadow_steps = std::max( a.max_shadow_steps, b.max_shadow_steps );
+	for (int i = 0; i < 12; i++) a.tail_profile[i] += b.tail_profile[i];
+	b = rtmi_stats{};
 }
 
 extern "C" {
@@ -2056,6 +2171,10 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		// earlier spellings of three of them
 		if (getenv( "RTMI_GRID_CLOSEST" )) sscanf( getenv( "RTMI_GRID_CLOSEST" ), "%u,%u", &c->grid_closest[0], &c->grid_closest[1] );
 		if (getenv( "RTMI_GRID_ANY" )) sscanf( getenv( "RTMI_GRID_ANY" ), "%u,%u", &c->grid_any[0], &c->grid_any[1] );
+		// Two lanes pay only when their streams do not share hardware queues: 2 x (main, side, 4 tails) + the caller's.  HIP gives a
+		// process GPU_MAX_HW_QUEUES of them (4 unless the process raised it before the runtime started): measured at 20 bench
+		// steps, 2 lanes on 16 queues +8.5 % rays/s, on 4 queues -2 %.
+		if (!getenv( "RTMI_LANES" )) { const char* q = getenv( "GPU_MAX_HW_QUEUES" ); c->lanes = q && atoi( q ) >= 12 ? 2 : 1; }
 		if (!getenv( "RTMI_SLOTS" ))
 		{
 			const char* q = getenv( "GPU_MAX_HW_QUEUES" );
@@ -2082,7 +2201,7 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 	const float aspect = (float)width / (float)height;
 	c->cam.pos = make_float4( 0, 0, -2, 0 ), c->cam.tl = make_float4( -aspect, 1, 0, 0 ), c->cam.tr = make_float4( aspect, 1, 0, 0 ), c->cam.bl = make_float4( -aspect, -1, 0, 0 );
 	*out = c;
-	return RTMI_OK;
+	return RTMI_OK; // (the second lane, if asked for, is made at the first render that can use it: rtmi_render)
 }
 
 int rtmi_destroy( rtmi_ctx* c )
@@ -2090,6 +2209,10 @@ int rtmi_destroy( rtmi_ctx* c )
 	if (!c) return RTMI_ERR_INVALID;
 	(void)hipSetDevice( c->device );
 	(void)hipDeviceSynchronize();
+	if (c->child) { c->lanes = 1; (void)set_lanes( c ); }
+	if (c->prof_base && !c->is_child) (void)hipEventDestroy( c->prof_base );
+	if (c->ev_fork) (void)hipEventDestroy( c->ev_fork );
+	if (c->ev_join) (void)hipEventDestroy( c->ev_join );
 	resolve_timers( c );
 	free_scene( c ), free_batches( c ), free_carry( c );
 	void* ps[] = { c->seeds, c->accum_own, c->pixels, c->pixels2, c->gamma_lut, c->frames, c->late, c->odd, c->carry_ctr, c->hook_buf };
@@ -2477,6 +2600,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 
 	free_scene( c );
 	free_batches( c ); // the suspend records are sized by the stack depth
+	if (c->child) free_batches( c->child );
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
 	c->walk_depth = std::max( c->stack_depth, wideNeed + 1 );
@@ -2581,8 +2705,9 @@ static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_be
 // One batch of S samples.  On the handle's stream: ray generation over all S*W*H slots, then queue-driven bounces until
 // few paths are left.  On the slot's stream, after the bulk: k_tail runs the remaining paths to their ends, then
 // k_accumulate (after the previous batch's).  The call returns with all of it enqueued.
-static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride )
+static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride, uint64_t ticket )
 {
+	Turn turn( c->chain, ticket ); // passes the turn on when this function returns, wherever it returns
 	const int WH = c->W * c->H;
 	const uint32_t N = (uint32_t)( (size_t)S * WH );
 	hipStream_t s = c->stream;
@@ -2728,22 +2853,32 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		else launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 11, last );
 		c->stats.bounce_launches++;
 	}
-	if (c->last_acc) HIPCHK( hipStreamWaitEvent( ts, c->last_acc, 0 ) ); // accumulate in batch order
+	turn.enter(); // accumulate in batch order: the previous batch (of either lane) has recorded its event
+	if (c->chain->last_acc) HIPCHK( hipStreamWaitEvent( ts, c->chain->last_acc, 0 ) );
 	if (S != 0)
 	{
 		ScopedTimer t( c, 3, ts );
 		hipLaunchKernelGGL( k_accumulate, dim3( nblocks( WH ) ), dim3( BLOCK ), 0, ts, c->accum, b.E, b.Es, WH, S );
 	}
 	HIPCHK( hipEventRecord( b.acc_done, ts ) );
-	b.busy = true, c->last_acc = b.acc_done;
+	b.busy = true, c->chain->last_acc = b.acc_done;
+	turn.leave();
 	HIPCHK( hipGetLastError() );
 	return RTMI_OK;
 }
 
 static int fetch_counters( rtmi_ctx* c )
 {
-	int r = sync_all( c );
+	int r = c->is_child ? RTMI_OK : sync_all( c ); // (the parent's sync_all covers the child)
 	if (r) return r;
+	if (c->child)
+	{
+		if (( r = fetch_counters( c->child ) )) { c->err = c->child->err; return r; }
+		resolve_timers( c->child );
+		merge_stats( c->stats, c->child->stats );
+		c->ext_intervals.insert( c->ext_intervals.end(), c->child->ext_intervals.begin(), c->child->ext_intervals.end() );
+		c->child->ext_intervals.clear();
+	}
 	for (int k = 0; k <= MAX_SLOTS; k++)
 	{
 		DevCounters h;
@@ -2778,19 +2913,54 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		// the interactive loop): there is no bulk for its tail to run beside, and the read that follows finds the host still
 		// enqueuing when the first tail rounds decide (k_tail_decide) -- they run for latency from the start
 		*(volatile uint32_t*)c->draining = sample_count <= S && (unsigned long long)S * WH <= c->carry_min ? 1u : 0u;
+		const int n_batches = ( sample_count + S - 1 ) / S;
+		// the second lane: made when first needed (more than one batch of more than carry_min paths), brought in line every time
+		if (c->lanes >= 2 && !c->child && n_batches >= 2 && (unsigned long long)S * WH > c->carry_min) { int r = set_lanes( c ); if (r) return r; }
+		rtmi_ctx* k = c->child && ( n_batches >= 2 || ( c->batch_seq & 1 ) ) && (unsigned long long)S * WH > c->carry_min ? c->child : 0;
+		if (k) { int r = sync_child( c ); if (r) { c->err = k->err.empty() ? c->err : k->err; return r; } *(volatile uint32_t*)k->draining = 0; }
 		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
-		for (int k = 0; k < c->n_slots; k++) { int r = ensure_batch( c, c->slots[k], S ); if (r) return r; }
-		for (int done = 0; done < sample_count; done += S)
+		for (int i = 0; i < c->n_slots; i++) { int r = ensure_batch( c, c->slots[i], S ); if (r) return r; }
+		if (k) for (int i = 0; i < k->n_slots; i++) { int r = ensure_batch( k, k->slots[i], S ); if (r) { c->err = k->err; return r; } }
+		if (k)
 		{
-			const int n = std::min( S, sample_count - done );
-			BatchSlot& b = c->slots[c->next_slot]; // batches rotate over the slots so that one's tail overlaps the next one's bulk
-			c->next_slot = ( c->next_slot + 1 ) % c->n_slots;
-			int r = ensure_batch( c, b, S );
-			if (r) return r;
-			if (( r = render_batch( c, b, sample_begin + done * sample_stride, n, sample_stride ) )) return r;
+			// the child's stream follows what the caller has enqueued on the handle's stream so far
+			HIPCHK( hipEventRecord( c->ev_fork, c->stream ) );
+			HIPCHK( hipStreamWaitEvent( k->stream, c->ev_fork, 0 ) );
 		}
+		uint64_t t0;
+		{ std::lock_guard<std::mutex> lock( c->chain->m ); t0 = c->chain->next_ticket; c->chain->next_ticket += (uint64_t)n_batches; }
+		// batch j of this call: samples [j*S, ...), ticket t0 + j (the order of the accumulates); lane = parity of the running
+		// batch number, so that consecutive calls of one batch each alternate too
+		auto run_lane = [&]( rtmi_ctx* l, int parity ) -> int {
+			(void)hipSetDevice( l->device );
+			for (int j = 0; j < n_batches; j++)
+			{
+				const bool mine = !k || (int)( ( c->batch_seq + (uint64_t)j ) & 1 ) == parity;
+				if (!mine) continue;
+				const int done = j * S, n = std::min( S, sample_count - done );
+				BatchSlot& b = l->slots[l->next_slot]; // batches rotate over the slots so that one's tail overlaps the next one's bulk
+				l->next_slot = ( l->next_slot + 1 ) % l->n_slots;
+				int r = render_batch( l, b, sample_begin + done * sample_stride, n, sample_stride, t0 + (uint64_t)j );
+				if (r)
+				{
+					// the batches of this lane that will not be rendered still have to pass their turns on
+					for (int jj = j + 1; jj < n_batches; jj++) if (!k || (int)( ( c->batch_seq + (uint64_t)jj ) & 1 ) == parity) { Turn skip( c->chain, t0 + (uint64_t)jj ); }
+					return r;
+				}
+			}
+			return RTMI_OK; };
+		int r = RTMI_OK, rk = RTMI_OK;
+		if (k)
+		{
+			std::thread th( [&] { rk = run_lane( k, 1 ); } );
+			r = run_lane( c, 0 );
+			th.join();
+			if (rk && !r) c->err = k->err, r = rk;
+		}
+		else r = run_lane( c, 0 );
+		c->batch_seq += (uint64_t)n_batches;
 		// counters are folded into the stats lazily (rtmi_get_stats), no sync here
-		return RTMI_OK;
+		return r;
 	}
 	if (mode < 0 || mode > RTMI_PATHTRACING) return fail( c, RTMI_ERR_INVALID, "unknown mode" );
 	if (max_depth < 1 || max_depth > 64) return fail( c, RTMI_ERR_INVALID, "max_depth must be 1..64" );
@@ -3024,8 +3194,26 @@ int rtmi_reduce_accumulator( rtmi_ctx* c, void* comm, int root )
 int rtmi_set_profiling( rtmi_ctx* c, int ev, int cn )
 {
 	if (!c) return RTMI_ERR_INVALID;
+	if (ev && !c->prof_events)
+	{
+		HIPCHK( hipSetDevice( c->device ) );
+		if (!c->prof_base && hipEventCreate( &c->prof_base ) != hipSuccess) c->prof_base = 0;
+		if (c->prof_base) { HIPCHK( hipEventRecord( c->prof_base, c->stream ) ); HIPCHK( hipEventSynchronize( c->prof_base ) ); }
+	}
 	c->prof_events = ev != 0, c->count_nodes = cn != 0;
 	return RTMI_OK;
+}
+// the length of the union of the closest-hit walk launches' intervals (they overlap when two lanes render side by side)
+static double union_ms( std::vector<std::pair<float, float>> v )
+{
+	std::sort( v.begin(), v.end() );
+	double total = 0; float hi = -1e30f;
+	for (auto& i : v)
+	{
+		if (i.first > hi) total += i.second - i.first, hi = i.second;
+		else if (i.second > hi) total += i.second - hi, hi = i.second;
+	}
+	return total;
 }
 int rtmi_get_stats( rtmi_ctx* c, rtmi_stats* out )
 {
@@ -3034,6 +3222,7 @@ int rtmi_get_stats( rtmi_ctx* c, rtmi_stats* out )
 	int r = fetch_counters( c );
 	if (r) return r;
 	resolve_timers( c );
+	c->stats.ms_extend_union = union_ms( c->ext_intervals );
 	*out = c->stats;
 	return RTMI_OK;
 }
@@ -3045,6 +3234,7 @@ int rtmi_reset_stats( rtmi_ctx* c )
 	if (r) return r;
 	resolve_timers( c );
 	c->stats = rtmi_stats{};
+	c->ext_intervals.clear();
 	return RTMI_OK;
 }
 

@@ -182,6 +182,7 @@ def test_full_size_image_and_properties(full):
     # arithmetic: same bits.  check_launches synchronises per bounce
     for opts in (dict(tail_team=0, tail_wave=0, check_launches=1), dict(tail_team=1, tail_wave=0), dict(tail_team=0, tail_wave=1, wave_below=1 << 16),
                  dict(batch=1, carry_min=0),  # four batches that hand their late paths on, although each is small enough to finish its own (carry_min)
+                 dict(lanes=2, batch=1, carry_min=0),  # two lanes: every other batch is enqueued by a second host thread on a pipeline of its own
                  dict(veteran_rounds=1, batch=1, carry_min=0)):  # ... and the paths carried twice stay with the batch they rode (k_carry_out)
         d4 = api.Device(W, H, **opts)
         d4.upload(scene.desc)
