@@ -2175,6 +2175,9 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 		// process GPU_MAX_HW_QUEUES of them (4 unless the process raised it before the runtime started): measured at 20 bench
 		// steps, 2 lanes on 16 queues +8.5 % rays/s, on 4 queues -2 %.
 		if (!getenv( "RTMI_LANES" )) { const char* q = getenv( "GPU_MAX_HW_QUEUES" ); c->lanes = q && atoi( q ) >= 12 ? 2 : 1; }
+		// beside another lane's kernels 3 resident walk blocks per CU and 8 tail waves per CU do better than 4 and 16
+		// (20 bench steps: 10 358 -> 10 623 Mrays/s; alone, 4 and 16 are the optimum)
+		if (c->lanes == 2) { if (!getenv( "RTMI_BLOCKS_PER_CU" )) c->blocks_per_cu_opt = 3; if (!getenv( "RTMI_TAIL_WAVES" )) c->tail_waves = 8; }
 		if (!getenv( "RTMI_SLOTS" ))
 		{
 			const char* q = getenv( "GPU_MAX_HW_QUEUES" );

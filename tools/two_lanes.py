@@ -19,7 +19,7 @@ def run(devs, spp_each, label):
     for d in devs: d.reset(); d.render(api.PATHTRACING, 0, spp_each, 1)
     for d in devs: d.flush(); d.sync(); d.reset(); d.reset_stats()
     def work(d, k):
-        for s in range(steps): d.render(api.PATHTRACING, (2 * s + k) * spp_each, spp_each, 1)
+        for s in range(steps): d.render(api.PATHTRACING, (len(devs) * s + k) * spp_each, spp_each, 1)
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(d, k)) for k, d in enumerate(devs)]
     for t in th: t.start()
@@ -31,7 +31,9 @@ def run(devs, spp_each, label):
     rays = sum(d.stats()["extend_rays"] + d.stats()["shadow_rays"] for d in devs)
     print("%-44s %7.1f ms/step enqueue, %7.1f ms/step with the drain (%5.0f ms), %6.0f Mrays/s" % (label, (t1 - t0) * 1e3 / steps, (t2 - t0) * 1e3 / steps, (t2 - t1) * 1e3, rays / (t2 - t0) / 1e6), flush=True)
 
-d = make(); run([d], 64, "one handle, batches of 16 spp"); d.close()
-d = make(batch=8); run([d], 64, "one handle, batches of 8 spp"); d.close()
-a, b = make(batch=8), make(batch=8); run([a, b], 32, "two handles, batches of 8 spp"); a.close(); b.close()
-a, b = make(), make(); run([a, b], 32, "two handles, batches of 16 spp"); a.close(); b.close()
+import os
+n = int(os.environ.get("HANDLES", "2"))
+opts = dict(lanes=int(os.environ.get("LANES", "1")))
+d = make(**opts); run([d], 64, "one handle (lanes=%d), batches of 16 spp" % opts["lanes"]); d.close()
+hs = [make(**opts) for _ in range(n)]; run(hs, 64 // n, "%d handles (lanes=%d), batches of 16 spp" % (n, opts["lanes"]))
+for h in hs: h.close()
