@@ -75,7 +75,7 @@ def parse():
 def committed_pmc():
     """PMC counters cannot be collected inside this run (rocprofv3 --pmc is its own pass per counter group): the figures of the
     committed passes of the same command (tools/profile_gpu.sh -> tools/traffic.py), newest round first.  Returns (dict, file)."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r02_traffic.json", "r02_lanes1_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)["kernels"]["k_trace<closest>"]
