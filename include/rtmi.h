@@ -114,6 +114,7 @@ typedef struct rtmi_stats {
 	double   ms_extend_union;   /* profiling mode: time during which at least one closest-hit walk launch was running.  With one lane
 	                               it equals ms_extend; with option lanes = 2 two launches (one per lane) overlap and each one's
 	                               own duration includes the time it shared the chip with the other */
+	double   ms_walk_union;     /* the same for the walk windows of ms_walk */
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,

@@ -93,7 +93,7 @@ class Stats(C.Structure):
                 ("extend_walkers", C.c_uint64), ("shadow_walkers", C.c_uint64),
                 ("suspended", C.c_uint64), ("max_extend_steps", C.c_uint64), ("max_shadow_steps", C.c_uint64),
                 ("ms_walk", C.c_double), ("n_walk_windows", C.c_uint64),
-                ("tail_profile", C.c_uint64 * 12), ("ms_drain", C.c_double), ("n_drains", C.c_uint64), ("ms_extend_union", C.c_double)]
+                ("tail_profile", C.c_uint64 * 12), ("ms_drain", C.c_double), ("n_drains", C.c_uint64), ("ms_extend_union", C.c_double), ("ms_walk_union", C.c_double)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k == "tail_profile" else getattr(self, k)) for k, _ in self._fields_}

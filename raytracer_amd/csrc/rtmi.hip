@@ -1670,6 +1670,7 @@ struct rtmi_ctx
 	std::vector<TimedEv> timed;
 	std::vector<hipEvent_t> ev_pool;
 	hipEvent_t prof_base = 0;    // recorded when event timing is switched on: launch intervals are taken relative to it
+	std::vector<std::pair<float, float>> walk_intervals; // the same for the walk windows
 	std::vector<std::pair<float, float>> ext_intervals; // [start, end) of the closest-hit walk launches since rtmi_reset_stats, ms after prof_base
 };
 
@@ -1761,7 +1762,12 @@ static void resolve_timers( rtmi_ctx* c )
 			}
 			else if (t.cls == 1) c->stats.ms_shade += ms, c->stats.n_shade_launches++;
 			else if (t.cls == 2) c->stats.ms_connect += ms, c->stats.n_connect_launches++;
-			else if (t.cls == 4) c->stats.ms_walk += ms, c->stats.n_walk_windows++;
+			else if (t.cls == 4)
+			{
+				c->stats.ms_walk += ms, c->stats.n_walk_windows++;
+				float t0 = 0;
+				if (c->prof_base && hipEventElapsedTime( &t0, c->prof_base, t.a ) == hipSuccess) c->walk_intervals.push_back( { t0, t0 + ms } );
+			}
 			else c->stats.ms_other += ms;
 		}
 		c->ev_pool.push_back( t.a ), c->ev_pool.push_back( t.b );
@@ -2881,6 +2887,8 @@ static int fetch_counters( rtmi_ctx* c )
 		merge_stats( c->stats, c->child->stats );
 		c->ext_intervals.insert( c->ext_intervals.end(), c->child->ext_intervals.begin(), c->child->ext_intervals.end() );
 		c->child->ext_intervals.clear();
+		c->walk_intervals.insert( c->walk_intervals.end(), c->child->walk_intervals.begin(), c->child->walk_intervals.end() );
+		c->child->walk_intervals.clear();
 	}
 	for (int k = 0; k <= MAX_SLOTS; k++)
 	{
@@ -3225,7 +3233,7 @@ int rtmi_get_stats( rtmi_ctx* c, rtmi_stats* out )
 	int r = fetch_counters( c );
 	if (r) return r;
 	resolve_timers( c );
-	c->stats.ms_extend_union = union_ms( c->ext_intervals );
+	c->stats.ms_extend_union = union_ms( c->ext_intervals ), c->stats.ms_walk_union = union_ms( c->walk_intervals );
 	*out = c->stats;
 	return RTMI_OK;
 }
@@ -3237,7 +3245,7 @@ int rtmi_reset_stats( rtmi_ctx* c )
 	if (r) return r;
 	resolve_timers( c );
 	c->stats = rtmi_stats{};
-	c->ext_intervals.clear();
+	c->ext_intervals.clear(), c->walk_intervals.clear();
 	return RTMI_OK;
 }
 
