@@ -83,7 +83,9 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 #define TAIL_WAITING 0x100u
 #define META_SLOT_MASK 0x01FFFFFFu  // a batch holds at most 2^25 paths
 #define META_AGE_SHIFT 25           // vertices behind the path, saturating at META_AGE_LATE
+#ifndef META_AGE_LATE
 #define META_AGE_LATE 15u
+#endif
 #define SQ_LATE 0x40000000u         // shadow queue slot word: the shadow ray left a late vertex
 #define META_SUSPENDED 0x20000000u // the closest-hit walk of this path was parked (k_trace); k_shade passes it through
 #define RESUME_BIT 0x80000000u     // walk queue entry / shadow slot field: resume from a suspend record
