@@ -14,16 +14,21 @@ pytestmark = pytest.mark.gpu
 W, H, SPP = 320, 180, 6
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, backend="gloo"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from raytracer_amd import api
     from raytracer_amd import distributed as D
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gpu = rank if backend == "nccl" else 0  # RCCL: one GPU per rank; gloo: both ranks share the box's one GPU
+    torch.cuda.set_device(gpu)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = api.HostScene.default()
-    d = api.Device(W, H, 0)
+    d = api.Device(W, H, gpu)
     d.upload(scene.desc)
     d.set_seeds(api.seed_table(W * H))
     d.set_camera(api.default_camera(W, H))
@@ -39,8 +44,12 @@ def _worker(rank, world, port, out_path):
     d.flush()
     # what a collective on this stream would read: a copy issued by torch on the caller's stream right after rtmi_flush (gloo
     # reduces host tensors; RCCL wants one GPU per rank and this box has one)
-    host = acc.cpu()
-    D.reduce_accumulator(host, dst=0)
+    if backend == "nccl":
+        D.reduce_accumulator(acc, dst=0)  # the device tensor itself, on the stream rtmi_flush has just ordered: bench.py's path
+        host = acc.cpu()
+    else:
+        host = acc.cpu()
+        D.reduce_accumulator(host, dst=0)
     if rank == 0:
         np.save(out_path, host.numpy())
     dist.barrier()
@@ -69,6 +78,28 @@ def test_two_gpu_ranks_equal_one(tmp_path):
     ref = Oracle(scene.desc).sample(W, H, api.default_camera(W, H), api.seed_table(W * H), 0, SPP)
     rmse = float(np.sqrt(np.mean((got[..., :3].astype(np.float64) - ref[..., :3]) ** 2))) / SPP
     assert rmse <= 1e-5  # bar 1e-3
+
+
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus(tmp_path):
+    """backend "nccl" (= RCCL), one GPU per rank, the device accumulators reduced directly after rtmi_flush -- what bench.py does
+    on the multi-GPU node.  Needs two GPUs: skipped on the one-GPU box."""
+    import torch
+    import torch.multiprocessing as mp
+    from raytracer_amd import api
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: RCCL wants a GPU per rank (the one-rank RCCL path is test_reduce_accumulator_inside_the_boundary)")
+    out = str(tmp_path / "acc_nccl.npy")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, out, "nccl"), nprocs=2, join=True)
+    got = np.load(out)
+    scene = api.HostScene.default()
+    d = api.Device(W, H, 0)
+    d.upload(scene.desc)
+    d.set_seeds(api.seed_table(W * H))
+    d.render(api.PATHTRACING, 0, SPP, 1)
+    one = d.accumulator()
+    d.close()
+    assert np.allclose(got, one, rtol=2e-6, atol=1e-6)
 
 
 def _load_rccl():
