@@ -1909,7 +1909,9 @@ static int join_batches( rtmi_ctx* c )
 		uint64_t t0;
 		{ std::lock_guard<std::mutex> lock( c->chain->m ); t0 = c->chain->next_ticket; c->chain->next_ticket += ( mine ? 1 : 0 ) + ( kids ? 1 : 0 ); }
 		std::thread th;
-		if (kids) th = std::thread( [&] { rk = join_lane( k, t0 ); } );
+		bool threaded = false;
+		if (kids && mine) { try { th = std::thread( [&] { rk = join_lane( k, t0 ); } ); threaded = true; } catch (...) {} } // (no thread to be had: one after the other, in ticket order)
+		if (kids && !threaded) rk = join_lane( k, t0 );
 		if (mine) r = join_lane( c, t0 + ( kids ? 1 : 0 ) );
 		if (th.joinable()) th.join();
 		if (rk) { c->err = k->err; return rk; }
@@ -2965,9 +2967,25 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		int r = RTMI_OK, rk = RTMI_OK;
 		if (k)
 		{
-			std::thread th( [&] { rk = run_lane( k, 1 ); } );
-			r = run_lane( c, 0 );
-			th.join();
+			std::thread th;
+			bool threaded = false;
+			try { th = std::thread( [&] { rk = run_lane( k, 1 ); } ); threaded = true; } catch (...) {}
+			if (threaded) { r = run_lane( c, 0 ); th.join(); }
+			else
+			{
+				// no thread to be had: both lanes from this one, batch by batch in ticket order (a batch takes its turn before it returns)
+				for (int j = 0; j < n_batches && !r && !rk; j++)
+				{
+					const bool childs = ( ( c->batch_seq + (uint64_t)j ) & 1 ) != 0;
+					rtmi_ctx* l = childs ? k : c;
+					(void)hipSetDevice( l->device );
+					const int done = j * S, n = std::min( S, sample_count - done );
+					BatchSlot& b = l->slots[l->next_slot];
+					l->next_slot = ( l->next_slot + 1 ) % l->n_slots;
+					int rr = render_batch( l, b, sample_begin + done * sample_stride, n, sample_stride, t0 + (uint64_t)j );
+					if (rr) { ( childs ? rk : r ) = rr; for (int jj = j + 1; jj < n_batches; jj++) { Turn skip( c->chain, t0 + (uint64_t)jj ); } }
+				}
+			}
 			if (rk && !r) c->err = k->err, r = rk;
 		}
 		else r = run_lane( c, 0 );
