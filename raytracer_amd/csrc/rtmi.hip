@@ -1629,7 +1629,11 @@ struct rtmi_ctx
 	bool paths_carried = false;  // some batch since the last join handed paths on (carry buffer, slot lists): the next batch, or join_batches, takes them in
 	uint32_t carry_min = 1u << 22; // option carry_min: a batch of no more camera paths than this finishes its own paths (see render_batch)
 	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
-	uint32_t small_paths = 1u << 18; // a batch with no more paths than this leaves the wavefront loop at once
+	int count_lag = 1;           // option count_lag: bounces after which a small batch's path counts are read (see render_batch)
+	// option small_paths: a batch with no more paths than this leaves the wavefront loop at once.  Renderer::Tick at 1280x720
+	// (0.92 M paths per frame): 2^17 5.92 ms, 2^18 5.32, 2^19 4.91, 2^20 4.72 -- below a million paths a wavefront bounce is
+	// launch latency (0.28 ms each) and the tail kernel's 32 bounces in one launch are cheaper; the 20-step bench does not care
+	uint32_t small_paths = 1u << 20;
 	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
@@ -2006,7 +2010,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 }, { "lanes", 1, 2 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 }, { "lanes", 1, 2 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -2044,6 +2048,8 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "wave_below" )) c->wave_below = (uint32_t)v;
 	else if (is( "veteran_rounds" )) c->veteran_rounds = (int)v;
 	else if (is( "carry_min" )) c->carry_min = (uint32_t)v;
+	else if (is( "small_paths" )) c->small_paths = (uint32_t)v;
+	else if (is( "count_lag" )) c->count_lag = (int)v;
 	else if (is( "lanes" )) { c->lanes = (int)v; if (live) { int r = set_lanes( c ); if (r) return r; } }
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
@@ -2077,7 +2083,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag;
 	found = false;
 	return 0;
 }
@@ -2093,7 +2099,7 @@ static int sync_child( rtmi_ctx* c )
 	k->overlap_on = c->overlap_on && k->side != 0, k->wide_on = c->wide_on, k->refill = c->refill, k->max_blocks = c->max_blocks;
 	for (int i = 0; i < 2; i++) k->grid_closest[i] = c->grid_closest[i], k->grid_any[i] = c->grid_any[i];
 	k->cam = c->cam, k->seeds = c->seeds, k->accum = c->accum, k->late = c->late, k->odd = c->odd;
-	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
+	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->count_lag = c->count_lag, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
 	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense, k->tail_mid = c->tail_mid;
 	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
 	k->veteran_rounds = c->veteran_rounds, k->tail_team = c->tail_team, k->tail_profile = c->tail_profile, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
@@ -2815,12 +2821,16 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			HIPCHK( hipStreamSynchronize( s ) );
 			if (c->side) HIPCHK( hipStreamSynchronize( c->side ) );
 		}
-		if (bounce >= 2)
+		// the path count comes back two bounces late, so that the host never waits for the bounce it has just enqueued; a small batch
+		// with nothing beside it (a frame of the interactive loop) reads it one bounce late: its bounces are launch-latency bound,
+		// and every one it runs beyond the switch to the tail is 0.3 ms of the frame
+		const int lag = last && S != 0 ? c->count_lag : 2;
+		if (bounce >= lag)
 		{
-			const int old = ( bounce - 2 ) & 3;
+			const int old = ( bounce - lag ) & 3;
 			HIPCHK( hipEventSynchronize( b.count_ev[old] ) );
 			upper = std::min( upper, b.host_counts[old] );
-			if (c->log_bounces && ( bounce < 64 || ( bounce & ( bounce - 1 ) ) == 0 )) fprintf( stderr, "rtmi: bounce %d starts with %u paths\n", bounce - 1, b.host_counts[old] );
+			if (c->log_bounces && ( bounce < 64 || ( bounce & ( bounce - 1 ) ) == 0 )) fprintf( stderr, "rtmi: bounce %d starts with %u paths\n", bounce + 1 - lag, b.host_counts[old] );
 		}
 		if (upper == 0) break;
 	}
