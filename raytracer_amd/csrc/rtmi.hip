@@ -1658,10 +1658,14 @@ struct rtmi_ctx
 	int veteran_rounds = -1;
 	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
 	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
-	uint32_t team_below = 1u << 17; // option team_below.  Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds):
-	                            // k_tail alone 372 ms, teams below 16 k 349, below 64 k 296, below 128 k 281, below 256 k 282
+	uint32_t team_below = 1u << 16; // option team_below.  Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds),
+	                            // before k_tail_wave took more than 4 k paths: k_tail alone 372 ms, teams below 16 k 349, below 64 k 296, below 128 k 281, below 256 k 282
 	bool tail_wave = true;      // option tail_wave: ... and k_tail_wave (one path per wave) at or below wave_below live paths
-	uint32_t wave_below = 1u << 12; // = the resident waves k_tail_wave gets: a wave per path.  Above it a round is a matter of throughput (k_tail)
+	// option wave_below.  The late rounds (1 024 bounces and more) last as long as their longest path: bounces x latency of a bounce,
+	// 9 us in k_tail_wave against 31 us in a loaded k_tail_team -- worth it even when the 4 096 resident waves take four paths each
+	// one after the other.  End of a 20-step render (wave_below / team_below): 4 k / 128 k 425 ms (two lanes) 356 (one);
+	// 8 k / 64 k 362, 367; 16 k / 64 k 363, 328; 16 k / 16 k 372; 32 k / 128 k 411; 64 k / 128 k 461
+	uint32_t wave_below = 1u << 14;
 	// device scratch of the parity hooks and rtmi_postprocess, grown on demand and kept (no allocation per call)
 	void* hook_buf = 0; size_t hook_cap = 0;
 	uint32_t gamma_host[256]; float gamma_cached = 0; // host image of gamma_lut (lives as long as the copy needs it)
@@ -1829,7 +1833,7 @@ static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E,
 // unexpectedly large round is only slower.
 static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int cur, DevCounters* ctr, const Sinks& sinks, uint32_t upper, int first_round = 0, int last_round = 11, bool drain = false )
 {
-	const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves );
+	const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves ), drain_waves = (uint32_t)c->n_cus * 16u;
 	for (int round = first_round, len = 32 << first_round; round <= last_round; round++, len *= 2)
 	{
 		const int limit = round == 11 ? 0x7FFFFFFF : len;
@@ -1851,7 +1855,8 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
 		if (team_below > wave_below)
 		{
-			const uint32_t twaves = std::max( 1u, std::min( max_waves, std::min( upper, team_below ) ) ), tblocks = ( twaves + 3 ) / 4;
+			// (the draining kernels have the chip to themselves: 16 waves per CU whatever tail_waves says about tails beside a bulk)
+			const uint32_t twaves = std::max( 1u, std::min( drain_waves, std::min( upper, team_below ) ) ), tblocks = ( twaves + 3 ) / 4;
 			const size_t tlds = (size_t)c->walk_depth * 64u * sizeof( uint32_t ); // 4 waves x 16 teams, one column each
 			if (c->tail_profile)
 				hipLaunchKernelGGL( k_tail_team<true>, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, wave_below, ctr );
@@ -1862,7 +1867,7 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		{
 			// one wave per path, as many waves as the round can have paths (a wave that finds the pool empty leaves at once)
 			// (the rounds of 4096 bounces and more are for a handful of paths: fewer waves, cheaper to dispatch when they find nothing)
-			const uint32_t wwaves = std::max( 1u, std::min( round >= 7 ? 1024u : max_waves, std::min( upper, wave_below ) ) ), wblocks = ( wwaves + WAVE_WG - 1 ) / WAVE_WG;
+			const uint32_t wwaves = std::max( 1u, std::min( round >= 7 ? 1024u : drain_waves, std::min( upper, wave_below ) ) ), wblocks = ( wwaves + WAVE_WG - 1 ) / WAVE_WG;
 			if (c->tail_profile)
 				hipLaunchKernelGGL( k_tail_wave<true>, dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, wave_below, ctr );
 			else
