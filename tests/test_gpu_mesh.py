@@ -248,6 +248,34 @@ def test_postfx_full_hd_matches_oracle():
     d.close()
 
 
+def test_two_lanes_counters_and_timing(default_scene):
+    """Option lanes = 2: the second pipeline's counters and event timings are folded into the handle's stats -- the same rays as one
+    lane counts, and the union of the walk launches' intervals is no longer than their sum."""
+    W, H, SPP = 640, 360, 6
+    seeds = api.seed_table(W * H)
+    got = {}
+    for lanes in (1, 2):
+        d = api.Device(W, H, lanes=lanes, batch=1, carry_min=0)
+        d.upload(default_scene.desc)
+        d.set_seeds(seeds)
+        d.set_camera(api.default_camera(W, H))
+        d.set_profiling(True, False)
+        d.reset_stats()
+        d.render(api.PATHTRACING, 0, SPP, 1)
+        img = d.accumulator()
+        st = d.stats()
+        got[lanes] = (img, st)
+        d.close()
+    (img1, st1), (img2, st2) = got[1], got[2]
+    assert np.array_equal(bits(img1), bits(img2))
+    for k in ("primary_samples", "extend_rays", "shadow_rays", "extend_walkers", "shadow_walkers"):
+        assert st1[k] == st2[k] and st1[k] > 0, k
+    assert st2["n_extend_launches"] >= st1["n_extend_launches"] > 0
+    for st in (st1, st2):
+        assert 0 < st["ms_extend_union"] <= st["ms_extend"] * 1.0001 and 0 < st["ms_walk_union"] <= st["ms_walk"] * 1.0001
+    assert abs(st1["ms_extend_union"] - st1["ms_extend"]) <= 1e-3 * st1["ms_extend"]  # one lane: launches of one kernel never overlap
+
+
 def test_edge_cases_and_status_codes(default_scene):
     L = api.device_lib()
     d = api.Device(64, 36)
