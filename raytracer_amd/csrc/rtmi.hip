@@ -701,7 +701,8 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
 template <bool PROF>
 __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t team_below, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t team_below, DevCounters* ctr,
+	int stop_late )
 {
 	extern __shared__ uint32_t lds_stack[];
 	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
@@ -799,6 +800,9 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 				if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
 				if (!v.push_next) { alive = false; break; }
 				O = v.newO, D = v.newD;
+				// (stop_late: the round of a batch's stragglers -- paths that lag behind their batch because walks of theirs were
+				// parked -- ends for a path as soon as it is late: from then on it owes its batch nothing and rides the next ones)
+				if (stop_late && age == META_AGE_LATE) break;
 			}
 		}
 		// survivors of this round, compacted (one atomic per wave)
@@ -1656,6 +1660,7 @@ struct rtmi_ctx
 	// but the tails' waves beside the bulk cost more than that: 126.4 -> 140.5 ms per step.  A trapped path-bounce costs about
 	// 1 ns as a rider of the wavefront kernels and 2-3 ns in a tail kernel, wherever that tail runs.
 	int veteran_rounds = -1;
+	bool stop_late = true;      // option stop_late: a batch's stragglers leave its tail round as soon as they are late (k_tail) instead of after 32 bounces
 	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
 	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
 	uint32_t team_below = 1u << 16; // option team_below.  Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds),
@@ -1831,7 +1836,8 @@ static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E,
 // k_tail_team.  Which kernel a round belongs to is decided on the device (live count, draining flag): all are launched and the
 // ones whose round it is not return at once -- every kernel pulls its paths from a pool, so any grid size is correct and an
 // unexpectedly large round is only slower.
-static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int cur, DevCounters* ctr, const Sinks& sinks, uint32_t upper, int first_round = 0, int last_round = 11, bool drain = false )
+static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int cur, DevCounters* ctr, const Sinks& sinks, uint32_t upper, int first_round = 0, int last_round = 11, bool drain = false,
+	int stop_late = 0 )
 {
 	const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves ), drain_waves = (uint32_t)c->n_cus * 16u;
 	for (int round = first_round, len = 32 << first_round; round <= last_round; round++, len *= 2)
@@ -1849,10 +1855,10 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		hipLaunchKernelGGL( k_tail_decide, dim3( 1 ), dim3( 1 ), 0, ts, ctr, &ctr->n_state[cur], c->draining_dev, team_below, wave_below );
 		if (c->tail_profile)
 			hipLaunchKernelGGL( k_tail<true>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr, stop_late );
 		else
 			hipLaunchKernelGGL( k_tail<false>, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr );
+				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr, stop_late );
 		if (team_below > wave_below)
 		{
 			// (the draining kernels have the chip to themselves: 16 waves per CU whatever tail_waves says about tails beside a bulk)
@@ -2015,7 +2021,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 }, { "lanes", 1, 2 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 }, { "lanes", 1, 2 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -2055,6 +2061,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "carry_min" )) c->carry_min = (uint32_t)v;
 	else if (is( "small_paths" )) c->small_paths = (uint32_t)v;
 	else if (is( "count_lag" )) c->count_lag = (int)v;
+	else if (is( "stop_late" )) c->stop_late = v != 0;
 	else if (is( "lanes" )) { c->lanes = (int)v; if (live) { int r = set_lanes( c ); if (r) return r; } }
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
@@ -2088,7 +2095,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "stop_late" )) return c->stop_late; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag;
 	found = false;
 	return 0;
 }
@@ -2108,7 +2115,7 @@ static int sync_child( rtmi_ctx* c )
 	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense, k->tail_mid = c->tail_mid;
 	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
 	k->veteran_rounds = c->veteran_rounds, k->tail_team = c->tail_team, k->tail_profile = c->tail_profile, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
-	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base;
+	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->stop_late = c->stop_late;
 	int r = RTMI_OK;
 	if (k->carry_cap != c->carry_cap) { r = apply_option( k, "carry_cap", c->carry_cap, true ); if (r) return r; }
 	if (k->left_cap != c->left_cap) { r = apply_option( k, "left_cap", c->left_cap, true ); if (r) return r; }
@@ -2872,7 +2879,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			// what does not fit goes through the remaining rounds
 			// (with veterans: `veteran_rounds` more rounds -- 64, 128, ... bounces -- before the survivors go to the list)
 			const int first_rounds = veteran_from != 0xFFFFFFFFu ? std::min( c->veteran_rounds, 10 ) : 0;
-			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, first_rounds );
+			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, first_rounds, false, first_rounds == 0 && c->stop_late ? 1 : 0 );
 			hipLaunchKernelGGL( k_carry_out, dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, ts, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1], b.left, b.n_left, c->left_cap, 0xFFFFFFFFu );
 			hipLaunchKernelGGL( k_next_bounce, dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
 			cur ^= 1;
