@@ -13,7 +13,7 @@
 //                       one atomic per 1024-thread block (ballot + mbcnt prefix per wave, LDS scan across waves)
 //   k_trace<any>        any-hit walk of the shadow queue, E[slot] += contribution          (scene.h:369-379, renderer.cpp:339-344);
 //                       on a side stream, beside the next bounce's k_trace<closest> (render_batch)
-//   k_carry_out / _in   the paths still alive when a batch leaves the bounce loop are late (>= 15 vertices: they add to an
+//   k_carry_out / _in   the paths still alive when a batch leaves the bounce loop are late (>= 7 vertices, META_AGE_LATE: they add to an
 //                       exact per-pixel sum, see Sinks) and join the next batch's queue; k_tail runs what is left of a
 //                       render's paths to their ends when the caller reads the image
 //   k_accumulate        accumulator[p] += E[sample][p] in sample order                    (renderer.cpp:566-567)
@@ -81,11 +81,16 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 #define FLAG_SPECULAR 1u
 #define FLAG_INSIDE 2u
 #define TAIL_WAITING 0x100u
-#define META_SLOT_MASK 0x01FFFFFFu  // a batch holds at most 2^25 paths
-#define META_AGE_SHIFT 25           // vertices behind the path, saturating at META_AGE_LATE
-#ifndef META_AGE_LATE
-#define META_AGE_LATE 15u
+// The meta word: slot | age << RTMI_SLOT_BITS | META_SUSPENDED (bit 29) | flags << 30.  26 slot bits = batches of up to 2^26 paths
+// (32 spp at 1080p) and 3 bits of age: a path is LATE from its 7th vertex.  (25 bits: 16 spp, late from the 15th vertex -- round 1's
+// layout.  Measured, 20 bench steps: one lane 9 547 -> 10 360 Mrays/s, two lanes 10 945 -> 11 165; the larger launches lift the
+// closest-hit walk from 0.60 to 0.73-0.77 of its algorithmic roofline; twice the queue memory.)
+#ifndef RTMI_SLOT_BITS
+#define RTMI_SLOT_BITS 26
 #endif
+#define META_SLOT_MASK ( ( 1u << RTMI_SLOT_BITS ) - 1u )  // a batch holds at most 2^RTMI_SLOT_BITS paths
+#define META_AGE_SHIFT RTMI_SLOT_BITS           // vertices behind the path, saturating at META_AGE_LATE
+#define META_AGE_LATE ( ( 1u << ( 29 - RTMI_SLOT_BITS ) ) - 1u ) // the age field fills the bits between the slot and META_SUSPENDED
 #define SQ_LATE 0x40000000u         // shadow queue slot word: the shadow ray left a late vertex
 #define META_SUSPENDED 0x20000000u // the closest-hit walk of this path was parked (k_trace); k_shade passes it through
 #define RESUME_BIT 0x80000000u     // walk queue entry / shadow slot field: resume from a suspend record
@@ -228,9 +233,9 @@ __device__ __forceinline__ void add_shadow_contribution( long long* Es, float4* 
 	else add_odd( odd, slot % WH, c.x, c.y, c.z );
 }
 
-// Where a path's radiance goes.  Up to its 15th vertex a path adds into its own slot: E[slot] is the float chain of
+// Where a path's radiance goes.  Up to its 7th vertex (META_AGE_LATE) a path adds into its own slot: E[slot] is the float chain of
 // Renderer::Sample for that sample (light hits, shadow rays that needed no walk), Es[slot] the exact sum of its walked
-// shadow rays; k_accumulate adds both to the pixel in sample order.  From the 15th vertex on (a LATE vertex: the age is
+// shadow rays; k_accumulate adds both to the pixel in sample order.  From the 7th vertex on (a LATE vertex: the age is
 // a property of the path, not of the launch that happens to process it) every contribution goes to late[pixel], an exact
 // 64-bit fixed-point sum per pixel that is folded into the accumulator when the caller next reads it.  A late path owes
 // its batch nothing any more, so the batch's slot can be accumulated and reused while the path is still bouncing -- in
@@ -1638,7 +1643,7 @@ struct rtmi_ctx
 	// (0.92 M paths per frame): 2^17 5.92 ms, 2^18 5.32, 2^19 4.91, 2^20 4.72 -- below a million paths a wavefront bounce is
 	// launch latency (0.28 ms each) and the tail kernel's 32 bounces in one launch are cheaper; the 20-step bench does not care
 	uint32_t small_paths = 1u << 20;
-	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 15)
+	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 7; the bounces up to the 16th are large enough to be worth running here)
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
 	int sblock = 512;            // threads per block of k_primary / k_shade (RTMI_SBLOCK): blocks of 16 waves wait for a CU with 4 free
@@ -2021,7 +2026,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << 25 }, { "lanes", 1, 2 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -2165,7 +2170,7 @@ const char* rtmi_last_error( rtmi_ctx* c ) { return c ? c->err.c_str() : "null c
 
 int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 {
-	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << 25 )) return RTMI_ERR_INVALID; // a batch is at least one sample of every pixel, at most 2^25 paths (META_SLOT_MASK)
+	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << RTMI_SLOT_BITS )) return RTMI_ERR_INVALID; // a batch is at least one sample of every pixel, at most 2^25 paths (META_SLOT_MASK)
 	*out = 0;
 	rtmi_ctx* c = new rtmi_ctx;
 	c->device = device_id, c->W = width, c->H = height;
@@ -2755,7 +2760,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
 	// veterans (k_carry_out): the slots of the last sample plane that fits a batch; needs two planes and the carry
-	const uint32_t planes = (uint32_t)( ( 1ull << 25 ) / (unsigned)WH );
+	const uint32_t planes = (uint32_t)( ( 1ull << RTMI_SLOT_BITS ) / (unsigned)WH );
 	const uint32_t veteran_from = c->carry_on && c->veteran_rounds >= 0 && planes >= 2 ? ( planes - 1 ) * (uint32_t)WH : 0xFFFFFFFFu;
 	if (c->carry_on && c->paths_carried)
 	{
@@ -2944,8 +2949,8 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 	{
 		if (sample_count <= 0 || sample_stride <= 0 || sample_begin < 0) return fail( c, RTMI_ERR_INVALID, "bad sample range" );
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
-		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << 25 ) / WH ) );
-		if (c->batch_opt > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, c->batch_opt ), ( 1ll << 25 ) / WH ) );
+		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << RTMI_SLOT_BITS ) / WH ) );
+		if (c->batch_opt > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, c->batch_opt ), ( 1ll << RTMI_SLOT_BITS ) / WH ) );
 		// more bulk work is coming: the tails in flight run for throughput again.  Not so for a call of one small batch (a frame of
 		// the interactive loop): there is no bulk for its tail to run beside, and the read that follows finds the host still
 		// enqueuing when the first tail rounds decide (k_tail_decide) -- they run for latency from the start
