@@ -136,7 +136,7 @@ def test_full_size_image_and_properties(full):
         assert np.array_equal(bits(d.accumulator()), bits(four))
     finally:
         d.set_option("batch", 0)
-    # late paths (from their 15th vertex on) ride the following batches and add to an exact per-pixel sum;
+    # late paths (from their 7th vertex on) ride the following batches and add to an exact per-pixel sum;
     # with option carry = 0 every batch finishes all of its paths in a tail of its own.  Same paths, same arithmetic: the images
     # differ by float summation order only
     d0 = api.Device(W, H, carry=0)
