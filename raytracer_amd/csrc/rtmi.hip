@@ -1664,6 +1664,7 @@ struct rtmi_ctx
 	// runs this many extra rounds.  Measured (20 bench steps): the final wait falls from 357 ms to 208 ms (2 rounds) / 190 ms (3),
 	// but the tails' waves beside the bulk cost more than that: 126.4 -> 140.5 ms per step.  A trapped path-bounce costs about
 	// 1 ns as a rider of the wavefront kernels and 2-3 ns in a tail kernel, wherever that tail runs.
+	int last_round_bounces = 1 << 16; // see launch_tail_rounds
 	int veteran_rounds = -1;
 	bool stop_late = true;      // option stop_late: a batch's stragglers leave its tail round as soon as they are late (k_tail) instead of after 32 bounces
 	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
@@ -1847,7 +1848,13 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 	const uint32_t max_waves = (uint32_t)( c->n_cus * c->tail_waves ), drain_waves = (uint32_t)c->n_cus * 16u;
 	for (int round = first_round, len = 32 << first_round; round <= last_round; round++, len *= 2)
 	{
-		const int limit = round == 11 ? 0x7FFFFFFF : len;
+		// The last round is where a path ENDS if it is still alive: the reference's Sample has no bounce limit (renderer.cpp:251) and
+		// some paths never end -- total internal reflection inside the glass of albedo 1 whose absorption the `inside` quirk skips
+		// (sample 220 of the default scene at 1280x720 holds one: the CPU restatement does not return from it either).  A kernel
+		// that never finishes takes the GPU with it, so after the 65 504 bounces of the rounds before, the last round gives a path
+		// `last_round_bounces` more (option; 0 = no limit, the reference's behaviour) and then drops it: it has added whatever it
+		// was going to add many thousands of vertices ago.  The longest path seen to end by itself had 13 600 vertices.
+		const int limit = round == 11 ? ( c->last_round_bounces > 0 ? c->last_round_bounces : 0x7FFFFFFF ) : len;
 		const bool coop = drain && c->ds.wide && round > 0;
 		const uint32_t wave_below = coop && c->tail_wave ? c->wave_below : 0u;
 		const uint32_t team_below = std::max( wave_below, coop && c->tail_team ? c->team_below : 0u ); // k_tail yields at or below this
@@ -2026,7 +2033,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "last_round_bounces", 0, 1 << 30 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -2067,6 +2074,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "small_paths" )) c->small_paths = (uint32_t)v;
 	else if (is( "count_lag" )) c->count_lag = (int)v;
 	else if (is( "stop_late" )) c->stop_late = v != 0;
+	else if (is( "last_round_bounces" )) c->last_round_bounces = (int)v;
 	else if (is( "lanes" )) { c->lanes = (int)v; if (live) { int r = set_lanes( c ); if (r) return r; } }
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
@@ -2100,7 +2108,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "stop_late" )) return c->stop_late; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "last_round_bounces" )) return c->last_round_bounces; if (is( "stop_late" )) return c->stop_late; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag;
 	found = false;
 	return 0;
 }
@@ -2120,7 +2128,7 @@ static int sync_child( rtmi_ctx* c )
 	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense, k->tail_mid = c->tail_mid;
 	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
 	k->veteran_rounds = c->veteran_rounds, k->tail_team = c->tail_team, k->tail_profile = c->tail_profile, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
-	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->stop_late = c->stop_late;
+	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->stop_late = c->stop_late, k->last_round_bounces = c->last_round_bounces;
 	int r = RTMI_OK;
 	if (k->carry_cap != c->carry_cap) { r = apply_option( k, "carry_cap", c->carry_cap, true ); if (r) return r; }
 	if (k->left_cap != c->left_cap) { r = apply_option( k, "left_cap", c->left_cap, true ); if (r) return r; }

@@ -248,6 +248,32 @@ def test_postfx_full_hd_matches_oracle():
     d.close()
 
 
+def test_a_path_that_never_ends_is_ended(default_scene):
+    """The reference's Sample has no bounce limit (renderer.cpp:251) and sample 220 of the default scene at 1280x720 holds a path
+    that never ends (total internal reflection in the glass of albedo 1; the CPU restatement does not return from it either,
+    which is why this frame has no oracle image).  The library drops a path that is still alive after the tail rounds
+    (option last_round_bounces): the frame comes back, finite, and the frames around it are unaffected."""
+    import time
+    W, H = 1280, 720
+    d = api.Device(W, H)
+    assert d.get_option("last_round_bounces") == 1 << 16
+    d.upload(default_scene.desc)
+    seeds = api.seed_table(W * H)
+    d.set_seeds(seeds)
+    d.set_camera(api.default_camera(W, H))
+    d.render(api.PATHTRACING, 219, 1, 1)
+    before = d.accumulator()
+    d.reset()
+    t0 = time.perf_counter()
+    d.render(api.PATHTRACING, 220, 1, 1)
+    img = d.accumulator()
+    assert time.perf_counter() - t0 < 20.0
+    assert np.isfinite(img).all() and img[..., :3].max() > 0
+    ref = Oracle(default_scene.desc).sample(W, H, api.default_camera(W, H), seeds, 219, 1)
+    assert rmse(before[..., :3], ref[..., :3]) <= 1e-5
+    d.close()
+
+
 def test_two_lanes_counters_and_timing(default_scene):
     """Option lanes = 2: the second pipeline's counters and event timings are folded into the handle's stats -- the same rays as one
     lane counts, and the union of the walk launches' intervals is no longer than their sum."""
