@@ -1,0 +1,18 @@
+"""tools/soak_mesh.py [frames] -- the 1 M-triangle scene, one sample per frame and a read, many frames (looks for a frame that never ends)"""
+import sys, time
+sys.path.insert(0, ".")
+from raytracer_amd import api
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+W, H = 1920, 1080
+scene = api.mesh_scene(1000000, api.BINNED_SAH)
+d = api.Device(W, H)
+d.upload(scene.desc); d.set_seeds(api.seed_table(W * H)); d.set_camera(api.default_camera(W, H, scene.scale))
+t0 = time.perf_counter()
+for i in range(T):
+    d.render(api.PATHTRACING, i, 1, 1)
+    d.finalize(i + 1)
+    if i % 50 == 49:
+        t1 = time.perf_counter()
+        print("frames %d-%d: %.2f ms per frame" % (i - 49, i, (t1 - t0) / 50 * 1e3), flush=True)
+        t0 = t1
+d.close()
