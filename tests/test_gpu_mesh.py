@@ -248,6 +248,33 @@ def test_postfx_full_hd_matches_oracle():
     d.close()
 
 
+def test_call_patterns_give_the_same_bits(full):
+    """However the samples are spread over rtmi_render calls, batches (large ones that hand their late paths on, small ones that
+    finish their own) and lanes, the accumulator holds the same bits."""
+    scene, _, seeds = full
+    W, H = 1920, 1080
+    cam = api.default_camera(W, H, scene.scale)
+
+    def run(calls, **o):
+        d = api.Device(W, H, **o)
+        d.upload(scene.desc)
+        d.set_seeds(seeds)
+        d.set_camera(cam)
+        b = 0
+        for n in calls:
+            d.render(api.PATHTRACING, b, n, 1)
+            b += n
+        img, st = d.accumulator(), d.stats()
+        d.close()
+        return bits(img), st
+
+    ref, st0 = run([11], lanes=1, batch=4)
+    for calls, o in (([11], dict(lanes=2, batch=4)), ([4, 4, 1, 1, 1], dict(lanes=2, batch=4)), ([1, 5, 1, 4], dict(lanes=2, batch=4)), ([3, 8], dict(lanes=1, batch=3))):
+        img, st = run(calls, **o)
+        assert np.array_equal(img, ref), (calls, o)
+        assert st["extend_rays"] == st0["extend_rays"] and st["shadow_rays"] == st0["shadow_rays"]
+
+
 def test_a_path_that_never_ends_is_ended(default_scene):
     """The reference's Sample has no bounce limit (renderer.cpp:251) and sample 220 of the default scene at 1280x720 holds a path
     that never ends (total internal reflection in the glass of albedo 1; the CPU restatement does not return from it either,
