@@ -10,6 +10,8 @@
 // tests/test_oracle_vs_ref.py) and the golden vectors generated from that build (tests/golden/*.npz, tools/make_golden.py,
 // tests/test_oracle_golden.py) -- bit for bit, but a build behind stand-ins does not count as the reference.  The camera
 // script at the end of this file (round 2) has no such cross-check at all: it restates camera.h:95-159 by reading.
+// Like the reference (Renderer::Sample has no bounce limit, renderer.cpp:251) orc_sample does not return from a path that never
+// ends: sample 220 of the default scene at 1280x720 holds one.  The product ends such a path (rtmi option last_round_bounces).
 //
 // Plain C++ with scalar binary32 arithmetic in the reference's operation order; build with
 // g++ -O2 -ffp-contract=off -fno-fast-math (no FMA, no reassociation).  Input is the same flat scene description
