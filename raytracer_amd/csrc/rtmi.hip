@@ -2970,7 +2970,18 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		if (k) { int r = sync_child( c ); if (r) { c->err = k->err.empty() ? c->err : k->err; return r; } *(volatile uint32_t*)k->draining = 0; }
 		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
 		for (int i = 0; i < c->n_slots; i++) { int r = ensure_batch( c, c->slots[i], S ); if (r) return r; }
-		if (k) for (int i = 0; i < k->n_slots; i++) { int r = ensure_batch( k, k->slots[i], S ); if (r) { c->err = k->err; return r; } }
+		if (k) for (int i = 0; i < k->n_slots; i++)
+		{
+			if (ensure_batch( k, k->slots[i], S ) == RTMI_OK) continue;
+			// no memory for a second set of queues: finish what is in flight, give the lane up and go on with one
+			fprintf( stderr, "rtmi_render: the second lane's queues do not fit in device memory (%s): rendering on one lane\n", k->err.c_str() );
+			{ int r = join_batches( c ); if (r) return r; }
+			{ int r = sync_all( c ); if (r) return r; }
+			c->lanes = 1;
+			(void)set_lanes( c );
+			k = 0;
+			break;
+		}
 		if (k)
 		{
 			// the child's stream follows what the caller has enqueued on the handle's stream so far
