@@ -50,7 +50,7 @@ struct PathState
 	float4* o_t;    // ray origin, hit distance
 	float4* d_h;    // ray direction, hit object index (int bits)
 	float4* T_s;    // throughput, rng state (uint bits)
-	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel, 25 bits) | age << 25 (4 bits) | META_SUSPENDED | flags << 30
+	uint32_t* meta; // slot (= sample_in_batch * W*H + pixel, RTMI_SLOT_BITS bits) | age | META_SUSPENDED | flags << 30 (see below)
 };
 struct ShadowQueue // only the shadow rays that have to walk the BVH
 {
@@ -2178,7 +2178,7 @@ const char* rtmi_last_error( rtmi_ctx* c ) { return c ? c->err.c_str() : "null c
 
 int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 {
-	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << RTMI_SLOT_BITS )) return RTMI_ERR_INVALID; // a batch is at least one sample of every pixel, at most 2^25 paths (META_SLOT_MASK)
+	if (!out || width <= 0 || height <= 0 || (long long)width * height > ( 1ll << RTMI_SLOT_BITS )) return RTMI_ERR_INVALID; // a batch is at least one sample of every pixel, at most 2^RTMI_SLOT_BITS paths (META_SLOT_MASK)
 	*out = 0;
 	rtmi_ctx* c = new rtmi_ctx;
 	c->device = device_id, c->W = width, c->H = height;
