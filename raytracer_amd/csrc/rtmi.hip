@@ -1653,7 +1653,8 @@ struct rtmi_ctx
 	uint32_t tail_dense = 4096, tail_mid = 0; // k_tail: 64 paths per wave above tail_dense live paths, 16 above tail_mid, else tail_lanes
 	bool log_bounces = false;   // option log_bounces: print the path count per bounce (diagnostics)
 	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
-	int batch_opt = 0;          // option batch: samples per render batch (0 = as many as 2^25 paths allow)
+	int batch_opt = 0;          // option batch: samples per render batch (0 = as many as 2^RTMI_SLOT_BITS paths allow)
+	int fit_samples = 0;        // > 0: the largest batch whose queues were found to fit in device memory (rtmi_render)
 	int blocks_per_cu_opt = 0;  // option blocks_per_cu: resident walk blocks per CU (0 = min(4, what the LDS stack allows))
 	bool tail_paths_set = false;
 	bool check_launches = false; // option check_launches: synchronise and check after every bounce (localises a fault; slow)
@@ -2079,12 +2080,13 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
 	else if (is( "slots" ))
 	{
-		c->n_slots = (int)v, c->next_slot = 0;
+		c->n_slots = (int)v, c->next_slot = 0, c->fit_samples = 0;
 		if (live) for (int k = 0; k < c->n_slots; k++) { int r = init_slot( c, c->slots[k] ); if (r) return r; }
 	}
 	else if (is( "carry_cap" ) || is( "left_cap" ))
 	{
 		( is( "carry_cap" ) ? c->carry_cap : c->left_cap ) = (uint32_t)v;
+		c->fit_samples = 0;
 		if (live)
 		{
 			free_batches( c ); // the queues of a batch are sized for the paths carried in
@@ -2947,6 +2949,27 @@ static int fetch_counters( rtmi_ctx* c )
 	return RTMI_OK;
 }
 
+// Device memory ran out while the batch slots were being resized (rtmi_render): finish every path that is in flight or waiting
+// in a carry buffer with the queues that are left, then free all of them.  A slot whose resize failed holds nothing, and the
+// camera-less batch that finishes the carried paths (join_batches) needs one: the other slots go first, then it gets the smallest.
+static int drain_and_free( rtmi_ctx* c )
+{
+	(void)hipGetLastError(); // (the refused allocation is dealt with here, not by the next launch check)
+	int r = sync_all( c );
+	if (r) return r;
+	rtmi_ctx* both[2] = { c, c->child };
+	for (rtmi_ctx* l : both)
+	{
+		if (!l) continue;
+		for (int i = 0; i < MAX_SLOTS; i++) if (i != l->next_slot) free_batch( l->slots[i] );
+		if (l->carry_on && l->paths_carried && !l->slots[l->next_slot].E && ( r = ensure_batch( l, l->slots[l->next_slot], 1 ) )) { if (l != c) c->err = l->err; return r; }
+	}
+	if (( r = join_batches( c ) ) || ( r = sync_all( c ) )) return r;
+	free_batches( c );
+	if (c->child) free_batches( c->child );
+	return RTMI_OK;
+}
+
 int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int sample_stride, int max_depth, int anti_aliasing )
 {
 	if (!c) return RTMI_ERR_INVALID;
@@ -2959,28 +2982,44 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 		// samples in flight per batch: enough paths to fill the chip in the long bounce tail, bounded memory
 		int S = (int)std::max<long long>( 1, std::min<long long>( sample_count, ( 1ll << RTMI_SLOT_BITS ) / WH ) );
 		if (c->batch_opt > 0) S = (int)std::max<long long>( 1, std::min<long long>( std::min( sample_count, c->batch_opt ), ( 1ll << RTMI_SLOT_BITS ) / WH ) );
-		// more bulk work is coming: the tails in flight run for throughput again.  Not so for a call of one small batch (a frame of
-		// the interactive loop): there is no bulk for its tail to run beside, and the read that follows finds the host still
-		// enqueuing when the first tail rounds decide (k_tail_decide) -- they run for latency from the start
-		*(volatile uint32_t*)c->draining = sample_count <= S && (unsigned long long)S * WH <= c->carry_min ? 1u : 0u;
-		const int n_batches = ( sample_count + S - 1 ) / S;
-		// the second lane: made when first needed (more than one batch of more than carry_min paths), brought in line every time
-		if (c->lanes >= 2 && !c->child && n_batches >= 2 && (unsigned long long)S * WH > c->carry_min) { int r = set_lanes( c ); if (r) return r; }
-		rtmi_ctx* k = c->child && ( n_batches >= 2 || ( c->batch_seq & 1 ) ) && (unsigned long long)S * WH > c->carry_min ? c->child : 0;
-		if (k) { int r = sync_child( c ); if (r) { c->err = k->err.empty() ? c->err : k->err; return r; } *(volatile uint32_t*)k->draining = 0; }
-		// size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it
-		for (int i = 0; i < c->n_slots; i++) { int r = ensure_batch( c, c->slots[i], S ); if (r) return r; }
-		if (k) for (int i = 0; i < k->n_slots; i++)
+		// Size every slot now: an allocation in the middle of a pipelined sequence of batches would drain it.  The queues of a
+		// full-size batch are 19 GB per slot; on a GPU that has less to give (other users, other handles) first the second lane
+		// goes, then the batches get smaller until they fit -- the image does not depend on either, only the speed does.
+		if (c->fit_samples > 0) S = std::min( S, c->fit_samples );
+		int n_batches = 0;
+		rtmi_ctx* k = 0;
+		for (;;)
 		{
-			if (ensure_batch( k, k->slots[i], S ) == RTMI_OK) continue;
+			int r = RTMI_OK;
+			for (int i = 0; i < c->n_slots && !r; i++) r = ensure_batch( c, c->slots[i], S );
+			if (r)
+			{
+				if (r != RTMI_ERR_NOMEM || S == 1) return r;
+				const std::string why = c->err;
+				if (( r = drain_and_free( c ) )) return r;
+				S = ( S + 1 ) / 2, c->fit_samples = S;
+				fprintf( stderr, "rtmi_render: the queues of %d-sample batches do not fit in device memory (%s): trying batches of %d\n", 2 * S, why.c_str(), S );
+				c->err.clear();
+				continue;
+			}
+			// more bulk work is coming: the tails in flight run for throughput again.  Not so for a call of one small batch (a frame of
+			// the interactive loop): there is no bulk for its tail to run beside, and the read that follows finds the host still
+			// enqueuing when the first tail rounds decide (k_tail_decide) -- they run for latency from the start
+			*(volatile uint32_t*)c->draining = sample_count <= S && (unsigned long long)S * WH <= c->carry_min ? 1u : 0u;
+			n_batches = ( sample_count + S - 1 ) / S;
+			// the second lane: made when first needed (more than one batch of more than carry_min paths), brought in line every time
+			if (c->lanes >= 2 && !c->child && n_batches >= 2 && (unsigned long long)S * WH > c->carry_min) { if (( r = set_lanes( c ) )) return r; }
+			k = c->child && ( n_batches >= 2 || ( c->batch_seq & 1 ) ) && (unsigned long long)S * WH > c->carry_min ? c->child : 0;
+			if (!k) break;
+			if (( r = sync_child( c ) )) { c->err = k->err.empty() ? c->err : k->err; return r; }
+			*(volatile uint32_t*)k->draining = 0;
+			for (int i = 0; i < k->n_slots && !r; i++) r = ensure_batch( k, k->slots[i], S );
+			if (!r) break;
 			// no memory for a second set of queues: finish what is in flight, give the lane up and go on with one
 			fprintf( stderr, "rtmi_render: the second lane's queues do not fit in device memory (%s): rendering on one lane\n", k->err.c_str() );
-			{ int r = join_batches( c ); if (r) return r; }
-			{ int r = sync_all( c ); if (r) return r; }
-			c->lanes = 1;
+			if (( r = drain_and_free( c ) )) return r;
+			c->lanes = 1, k = 0;
 			(void)set_lanes( c );
-			k = 0;
-			break;
 		}
 		if (k)
 		{
