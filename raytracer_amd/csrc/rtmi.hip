@@ -1667,6 +1667,11 @@ struct rtmi_ctx
 	// 1 ns as a rider of the wavefront kernels and 2-3 ns in a tail kernel, wherever that tail runs.
 	int last_round_bounces = 1 << 16; // see launch_tail_rounds
 	int veteran_rounds = -1;
+	// option preview_reads: rtmi_finalize shows the image as far as it has got instead of finishing every path first -- the frame
+	// loop's display path (Renderer::Tick = one sample and a finalize per frame).  The paths of a frame that are still bouncing
+	// when it is shown (a few thousand of 2 M on the 1 M-triangle scene, inside the mirror and glass knots for thousands of
+	// bounces) ride the next frames' batches; every other read, rtmi_flush and a camera change join as before.
+	bool preview_reads = false;
 	bool stop_late = true;      // option stop_late: a batch's stragglers leave its tail round as soon as they are late (k_tail) instead of after 32 bounces
 	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
 	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
@@ -1921,13 +1926,23 @@ static int join_lane( rtmi_ctx* c, uint64_t ticket )
 	if (!r) c->paths_carried = false;
 	return r;
 }
-static int join_batches( rtmi_ctx* c )
+// `preview`: the caller wants the image as far as it has got (rtmi_finalize under option preview_reads): the accumulates in
+// flight and the late sums so far, but the carried paths stay where they are and ride the next batch.
+static int join_batches( rtmi_ctx* c, bool preview = false )
 {
 	rtmi_ctx* k = c->child;
 	if (c->draining) *(volatile uint32_t*)c->draining = 1; // the caller is about to wait for the tails
 	if (k && k->draining) *(volatile uint32_t*)k->draining = 1;
 	const bool pending = c->carry_pending || ( k && k->carry_pending );
 	if (pending && !c->drain_open) c->drain_open = true, c->drain_t0 = now_ms();
+	if (pending && c->has_scene && preview)
+	{
+		if (c->chain->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->chain->last_acc, 0 ) );
+		ScopedTimer t( c, 3, c->stream );
+		hipLaunchKernelGGL( k_fold_late, dim3( nblocks( (size_t)c->W * c->H ) ), dim3( BLOCK ), 0, c->stream, c->accum, c->late, c->odd, c->W * c->H );
+		HIPCHK( hipGetLastError() );
+		return RTMI_OK; // (carry_pending stays: the next full join finishes the carried paths)
+	}
 	if (pending && c->has_scene)
 	{
 		// The late paths that the last batches handed on have no batch to ride with: they get a batch of their own, without
@@ -2034,7 +2049,7 @@ static const OptDesc g_opts[] = {
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
 	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "last_round_bounces", 0, 1 << 30 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "last_round_bounces", 0, 1 << 30 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 }, { "preview_reads", 0, 1 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -2075,6 +2090,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "small_paths" )) c->small_paths = (uint32_t)v;
 	else if (is( "count_lag" )) c->count_lag = (int)v;
 	else if (is( "stop_late" )) c->stop_late = v != 0;
+	else if (is( "preview_reads" )) c->preview_reads = v != 0;
 	else if (is( "last_round_bounces" )) c->last_round_bounces = (int)v;
 	else if (is( "lanes" )) { c->lanes = (int)v; if (live) { int r = set_lanes( c ); if (r) return r; } }
 	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
@@ -2110,7 +2126,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
 	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
 	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "last_round_bounces" )) return c->last_round_bounces; if (is( "stop_late" )) return c->stop_late; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag;
+	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "last_round_bounces" )) return c->last_round_bounces; if (is( "stop_late" )) return c->stop_late; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag; if (is( "preview_reads" )) return c->preview_reads;
 	found = false;
 	return 0;
 }
@@ -2130,7 +2146,7 @@ static int sync_child( rtmi_ctx* c )
 	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense, k->tail_mid = c->tail_mid;
 	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
 	k->veteran_rounds = c->veteran_rounds, k->tail_team = c->tail_team, k->tail_profile = c->tail_profile, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
-	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->stop_late = c->stop_late, k->last_round_bounces = c->last_round_bounces;
+	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->stop_late = c->stop_late, k->last_round_bounces = c->last_round_bounces, k->preview_reads = c->preview_reads;
 	int r = RTMI_OK;
 	if (k->carry_cap != c->carry_cap) { r = apply_option( k, "carry_cap", c->carry_cap, true ); if (r) return r; }
 	if (k->left_cap != c->left_cap) { r = apply_option( k, "left_cap", c->left_cap, true ); if (r) return r; }
@@ -2765,7 +2781,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	// frame: Renderer::Tick) would only move its paths from one small launch to another, and when the caller reads right after it
 	// (Tick does) they would get a second batch of their own.  It finishes its paths itself: wavefront bounces down to
 	// small_paths, then the tail rounds, which run for latency if the host is already waiting when they start (k_tail_decide).
-	const bool last = S == 0 || N <= c->carry_min;
+	const bool last = S == 0 || ( N <= c->carry_min && !( c->preview_reads && c->carry_on ) );
 	if (S != 0) launch_primary( c, b, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
@@ -2797,6 +2813,9 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	auto close_window = [&]() { if (window) { hipEvent_t e = get_event( c ); if (e) { (void)hipEventRecord( e, s ); c->timed.push_back( { window, e, 4 } ); } else c->ev_pool.push_back( window ); window = 0; } };
 	const int min_bounce = c->carry_on && !last ? c->carry_bounce : 0; // with carry, a batch that is still large stays in the loop until its paths are late
 	const uint32_t tail_paths = last ? c->small_paths : c->tail_paths;
+	// a batch leaves the loop early once this few paths are left, whatever their age.  A small batch that hands its paths on
+	// (preview_reads) must not before they are late: what is not late goes through this batch's own tail, whose list holds left_cap
+	const uint32_t small = last || N > c->carry_min ? c->small_paths : std::min( c->small_paths, c->left_cap );
 	for (int bounce = 0;; bounce++)
 	{
 		// Near the end of the bulk: stop parking rays (so that no suspended state is left), one bounce later hand the
@@ -2804,8 +2823,8 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		// (a launch without parking lasts as long as its longest ray, 3x the parked one at this size: only the bounce before
 		// the hand-over runs that way; `upper` is two bounces old and the path count falls by about 0.83 per bounce)
 		const unsigned long long soon = (unsigned long long)( upper * 0.85 );
-		const bool prep = tail_paths && ( ( soon <= tail_paths && bounce + 1 >= min_bounce ) || soon <= c->small_paths );
-		if (tail_paths && clean >= 1 && ( ( upper <= tail_paths && bounce >= min_bounce ) || upper <= c->small_paths )) { tail = true; break; }
+		const bool prep = tail_paths && ( ( soon <= tail_paths && bounce + 1 >= min_bounce ) || soon <= small );
+		if (tail_paths && clean >= 1 && ( ( upper <= tail_paths && bounce >= min_bounce ) || upper <= small )) { tail = true; break; }
 		const int budget = prep ? 0 : c->budget;
 		clean = prep ? clean + 1 : 0;
 		if (bounce == 0 && c->overlap_on && c->prof_events) { window = get_event( c ); if (window) (void)hipEventRecord( window, s ); } // the first walk has a window to itself
@@ -3233,7 +3252,7 @@ int rtmi_finalize( rtmi_ctx* c, uint32_t* out, int frames, const rtmi_postfx* fx
 {
 	if (!c || !out) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
-	{ int r = join_batches( c ); if (r) return r; }
+	{ int r = join_batches( c, c->preview_reads ); if (r) return r; }
 	const int n = c->W * c->H;
 	{
 		ScopedTimer t( c, 3, c->stream );

@@ -301,6 +301,34 @@ def test_a_path_that_never_ends_is_ended(default_scene):
     d.close()
 
 
+def test_preview_reads_show_frames_early_and_lose_nothing(full):
+    """Option preview_reads: rtmi_finalize (what Renderer::Tick calls every frame) shows the image as far as it has got; the paths
+    still bouncing inside the mirror and glass knots ride the next frames' batches.  Nothing is lost: after the last frame a
+    joining read gives the image of the same samples rendered in one call, up to the rounding of the extra folds."""
+    scene, d, seeds = full
+    W, H, N = 1920, 1080, 6
+    d.reset()
+    d.render(api.PATHTRACING, 0, N, 1)
+    want = d.accumulator()
+    p = api.Device(W, H, preview_reads=1)
+    assert p.get_option("preview_reads") == 1
+    p.upload(scene.desc)
+    p.set_seeds(seeds)
+    p.set_camera(api.default_camera(W, H, scene.scale))
+    shown = None
+    for i in range(N):
+        p.render(api.PATHTRACING, i, 1, 1)
+        shown = p.finalize(i + 1)
+    full_px = d.finalize(N)
+    # the last preview is the finished image but for the few paths still in flight: nearly every pixel is already final
+    same = (shown == full_px).mean()
+    assert same > 0.95, same
+    got = p.accumulator()  # joins: the carried paths are finished now
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(p.finalize(N), full_px) or (p.finalize(N) == full_px).mean() > 0.9999  # RGB8 truncation can flip on a rounding
+    p.close()
+
+
 def test_two_lanes_counters_and_timing(default_scene):
     """Option lanes = 2: the second pipeline's counters and event timings are folded into the handle's stats -- the same rays as one
     lane counts, and the union of the walk launches' intervals is no longer than their sum."""

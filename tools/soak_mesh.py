@@ -5,7 +5,8 @@ from raytracer_amd import api
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 W, H = 1920, 1080
 scene = api.mesh_scene(1000000, api.BINNED_SAH)
-d = api.Device(W, H)
+import os
+d = api.Device(W, H, preview_reads=int(os.environ.get('PREVIEW', '0')))
 d.upload(scene.desc); d.set_seeds(api.seed_table(W * H)); d.set_camera(api.default_camera(W, H, scene.scale))
 t0 = time.perf_counter()
 for i in range(T):
