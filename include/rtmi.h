@@ -143,7 +143,9 @@ int rtmi_set_camera( rtmi_ctx*, const float cam[16] );
 /* Replaces seedBuffer (renderer.cpp:51-57): W*H xorshift32 outputs.  State of (pixel p, sample s) is
  * WangHash(seeds[p] + s*0x9E3779B9) (0 -> 1), SURVEY A.5. */
 int rtmi_set_seeds( rtmi_ctx*, const uint32_t* seeds );
-/* Replaces memset(accumulator) + accumulatorBuffer->CopyToDevice (renderer.cpp:622-633, renderer.h:43-77). */
+/* Replaces memset(accumulator) + accumulatorBuffer->CopyToDevice (renderer.cpp:622-633, renderer.h:43-77).  Ordered after the
+ * accumulates in flight; paths of earlier renders that are still bouncing are dropped with the image they belonged to (not
+ * finished first), so a camera that moves every frame does not pay for them.  Asynchronous on the handle's stream. */
 int rtmi_reset_accumulator( rtmi_ctx* );
 /* Accumulate into a caller-owned device buffer of W*H float4 (e.g. a torch tensor that torch.distributed reduces
  * over RCCL) instead of the handle's own accumulatorBuffer (renderer.cpp:23).  NULL restores the internal one. */

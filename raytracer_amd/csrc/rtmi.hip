@@ -2688,8 +2688,22 @@ int rtmi_reset_accumulator( rtmi_ctx* c )
 {
 	if (!c) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
-	{ int r = join_batches( c ); if (r) return r; } // accumulates still in flight come first
-	HIPCHK( hipMemsetAsync( c->accum, 0, (size_t)c->W * c->H * sizeof( float4 ), c->stream ) );
+	// The accumulates in flight come first (they write the accumulator).  The paths that wait in the carry buffers and slot lists,
+	// and the late sums, belong to the image that is being thrown away: they are dropped, not finished -- a camera that moves
+	// every frame (renderer.cpp:622-633) would otherwise pay for the longest paths of a frame nobody will see.
+	if (c->chain->last_acc) HIPCHK( hipStreamWaitEvent( c->stream, c->chain->last_acc, 0 ) );
+	rtmi_ctx* both[2] = { c, c->child };
+	for (rtmi_ctx* l : both)
+	{
+		if (!l) continue;
+		if (l->carry_ctr) HIPCHK( hipMemsetAsync( &l->carry_ctr->n_state[0], 0, sizeof( uint32_t ), c->stream ) );
+		for (auto& b : l->slots) if (b.n_left) HIPCHK( hipMemsetAsync( b.n_left, 0, sizeof( uint32_t ), c->stream ) );
+		l->paths_carried = false, l->carry_pending = false;
+	}
+	const size_t n = (size_t)c->W * c->H;
+	HIPCHK( hipMemsetAsync( c->late, 0, 4 * n * sizeof( long long ), c->stream ) );
+	HIPCHK( hipMemsetAsync( c->odd, 0, n * sizeof( float4 ), c->stream ) );
+	HIPCHK( hipMemsetAsync( c->accum, 0, n * sizeof( float4 ), c->stream ) );
 	return RTMI_OK;
 }
 int rtmi_set_accumulator( rtmi_ctx* c, void* p )
