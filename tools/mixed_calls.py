@@ -17,6 +17,7 @@ def run(calls, **o):
     d.close()
     return img.view(np.uint32), st
 ref, st0 = run([67], lanes=1)
-for calls, o in (([67], dict(lanes=2)), ([32, 32, 1, 1, 1], dict(lanes=2)), ([1, 33, 1, 32], dict(lanes=2)), ([5, 40, 22], dict(lanes=1)), ([64, 3], dict(lanes=2, batch=7))):
+for calls, o in (([67], dict(lanes=2)), ([32, 32, 1, 1, 1], dict(lanes=2)), ([1, 33, 1, 32], dict(lanes=2)), ([5, 40, 22], dict(lanes=1)), ([64, 3], dict(lanes=2, batch=7)),
+                 ([1, 1, 33, 1, 30, 1], dict(lanes=2, preview_reads=1)), ([1] * 12 + [55], dict(lanes=1, preview_reads=1))):
     img, st = run(calls, **o)
     print(calls, o, "bit-equal" if np.array_equal(img, ref) else "DIFFERENT %d" % int((img != ref).sum()), st["extend_rays"] == st0["extend_rays"], flush=True)
