@@ -88,8 +88,7 @@ struct DScene
 	const float4* __restrict__ cubes;   // per cube 8 x float4: invM rows 0..2, b0, b1, M rows 0..2
 	const float4* __restrict__ planes;  // (N, d)
 	// shading
-	const float4* __restrict__ primitives; // [total] scene.h:120-181
-	const uint8_t* __restrict__ mat_id;    // [total] -> materials
+	const float4* __restrict__ primitives; // [total] scene.h:120-181 (xyz); w = index into `materials` (uint bits, set on upload): one gather per hit, not two
 	const DMaterial* __restrict__ materials;
 	const float* __restrict__ sphere_invr;
 	const uint32_t* __restrict__ texture;
@@ -99,16 +98,22 @@ struct DScene
 	float light_A, light_s;
 	float4 wl_pos[2], wl_color[2];
 	float wl_intensity;
+	// quads[0] (the only quad the reference tests, scene.h:361) as kernel arguments: invT rows 0..2, {size,0,0,0}
+	float4 quad0[4];
+	// plane_pairs != 0: the scene has exactly the six planes +x, -x, +y, -y, +z, -z in this order (the reference's room,
+	// scene.h:70-75); pair_d[k] = d of plane k.  See isect_planes.
+	int plane_pairs;
+	float pair_d[6];
 };
 
 struct RayHit { float t; int obj; int pos; };
 
 // ---- primitive intersection (closest-hit forms) ---------------------------------------------------------------
 // Quad::Intersect, primitive.h:284-295
-__device__ __forceinline__ void isect_quad( const DScene& s, int i, f3 O, f3 D, RayHit& h )
+__device__ __forceinline__ void isect_quad( const DScene& s, int i, f3 O, f3 D, RayHit& h ) // (i == 0: every caller)
 {
-	m34 M; M.r0 = s.quads[4 * i], M.r1 = s.quads[4 * i + 1], M.r2 = s.quads[4 * i + 2];
-	const float size = s.quads[4 * i + 3].x;
+	m34 M; M.r0 = s.quad0[0], M.r1 = s.quad0[1], M.r2 = s.quad0[2];
+	const float size = s.quad0[3].x;
 	const f3 o = xform_pos( O, M ), d = xform_vec( D, M );
 	const float t = o.y / -d.y;
 	if (t < h.t && t > 0)
@@ -147,12 +152,50 @@ __device__ __forceinline__ void isect_plane( const DScene& s, int i, f3 O, f3 D,
 	const float t = -( dot3( O, N ) + p.w ) / ( dot3( D, N ) );
 	if (t < h.t && t > 0) h.t = t, h.obj = s.n_quads + s.n_spheres + s.n_cubes + i, h.pos = -1;
 }
+// Two opposite axis planes at once: plane k = (+e, d1), plane k + 1 = (-e, d2); o, dd = the ray's origin and direction
+// component on that axis.  With N = +-e the reference's dot products are the component itself (x * 1 + y * 0 + z * 0, exact for
+// finite rays up to the sign of a zero, which no outcome depends on: a zero numerator gives t = +-0, a zero denominator
+// t = +-inf or NaN, none of which passes `t < ray.t && t > 0`), so a = (O.N + d) and b = D.N of primitive.h:156 are o + d1, dd
+// and d2 - o, -dd.  An origin strictly between the two planes (a1 > 0 and a2 > 0: every ray that starts inside the room) can
+// only hit the one it faces -- t = -a / b > 0 needs b < 0 -- so ONE division serves the pair; the other plane's t is negative
+// and the reference rejects it.  Any other origin takes both tests as written.  Same t bits, same accept order (k before k + 1).
+__device__ __forceinline__ void isect_plane_pair( float o, float dd, float d1, float d2, int obj, RayHit& h )
+{
+	const float a1 = o + d1, a2 = d2 - o;
+	if (a1 > 0 && a2 > 0)
+	{
+		const bool first = dd < 0;
+		const float t = -( first ? a1 : a2 ) / ( first ? dd : -dd );
+		if (( dd < 0 || dd > 0 ) && t < h.t && t > 0) h.t = t, h.obj = obj + ( first ? 0 : 1 ), h.pos = -1;
+	}
+	else
+	{
+		const float t1 = -a1 / dd;
+		if (t1 < h.t && t1 > 0) h.t = t1, h.obj = obj, h.pos = -1;
+		const float t2 = -a2 / -dd;
+		if (t2 < h.t && t2 > 0) h.t = t2, h.obj = obj + 1, h.pos = -1;
+	}
+}
+// the plane loop of BVH::IntersectBVH (bvh.h:498-502): every plane in order, each accepted when closer than what came before.
+// (Scene::IsOccluded's loop, bvh.h:642-646 with the early out, asks only WHETHER some plane is closer than the ray's end: the
+// same function answers that through h.obj.)
+__device__ __forceinline__ void isect_planes( const DScene& s, f3 O, f3 D, RayHit& h )
+{
+	if (s.plane_pairs)
+	{
+		const int base = s.n_quads + s.n_spheres + s.n_cubes;
+		isect_plane_pair( O.x, D.x, s.pair_d[0], s.pair_d[1], base, h );
+		isect_plane_pair( O.y, D.y, s.pair_d[2], s.pair_d[3], base + 2, h );
+		isect_plane_pair( O.z, D.z, s.pair_d[4], s.pair_d[5], base + 4, h );
+	}
+	else for (int i = 0; i < s.n_planes; i++) isect_plane( s, i, O, D, h );
+}
 // the non-BVH part of Scene::FindNearest + the plane loop of BVH::IntersectBVH (scene.h:361-362, bvh.h:498-502)
 __device__ __forceinline__ void isect_analytic( const DScene& s, f3 O, f3 D, RayHit& h )
 {
 	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );   // the reference tests quads[0] and cubes[0] only
 	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
-	for (int i = 0; i < s.n_planes; i++) isect_plane( s, i, O, D, h );
+	isect_planes( s, O, D, h );
 }
 
 // One leaf-ordered primitive record against the ray.  Accepts a hit when it is closer, or equally far but
@@ -753,7 +796,8 @@ __device__ __forceinline__ bool is_occluded( const DScene& s, f3 O, f3 D, float 
 	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
 	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
 	if (h.obj != -1) return true;
-	for (int i = 0; i < s.n_planes; i++) { isect_plane( s, i, O, D, h ); if (h.obj != -1) return true; }
+	isect_planes( s, O, D, h );
+	if (h.obj != -1) return true;
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
@@ -806,15 +850,16 @@ struct HitAttr { f3 N; f3 albedo; const DMaterial* mat; };
 // wo = ray.D; WANT_ALBEDO mirrors where the reference calls GetAlbedo (renderer.cpp:145, 274, 324)
 __device__ __forceinline__ void hit_attributes( const DScene& s, int obj, f3 I, f3 wo, HitAttr& a )
 {
-	a.mat = &s.materials[s.mat_id[obj]];
+	const float4 pr = s.primitives[obj];
+	a.mat = &s.materials[__float_as_uint( pr.w )];
 	const f3 color = mk3( a.mat->color );
 	int k = obj;
 	f3 N;
-	if (k < s.n_quads) { N = mk3( s.primitives[obj] ); a.albedo = mk3( 10, 10, 10 ); }                    // primitive.h:296-304
-	else if (( k -= s.n_quads ) < s.n_spheres) { N = ( I - mk3( s.primitives[obj] ) ) * s.sphere_invr[k]; a.albedo = color; } // :128-131
+	if (k < s.n_quads) { N = mk3( pr ); a.albedo = mk3( 10, 10, 10 ); }                    // primitive.h:296-304
+	else if (( k -= s.n_quads ) < s.n_spheres) { N = ( I - mk3( pr ) ) * s.sphere_invr[k]; a.albedo = color; } // :128-131
 	else if (( k -= s.n_spheres ) < s.n_cubes) { N = cube_normal( s, k, I ); a.albedo = color; }
-	else if (( k -= s.n_cubes ) < s.n_planes) { N = mk3( s.primitives[obj] ); a.albedo = plane_albedo( s, N, I ); }
-	else { N = mk3( s.primitives[obj] ); a.albedo = color; }
+	else if (( k -= s.n_cubes ) < s.n_planes) { N = mk3( pr ); a.albedo = plane_albedo( s, N, I ); }
+	else { N = mk3( pr ); a.albedo = color; }
 	if (dot3( N, wo ) > 0) N = -N; // scene.h:412
 	a.N = N;
 }

@@ -159,7 +159,7 @@ __device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tm
 	RayHit h; h.t = tmaxRay, h.obj = -1, h.pos = -1;
 	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
 	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
-	for (int k = 0; k < s.n_planes && h.obj == -1; k++) isect_plane( s, k, O, D, h );
+	if (h.obj == -1) isect_planes( s, O, D, h );
 	occluded = h.obj != -1, walk = false;
 	if (occluded || s.n_bvh_prims == 0) return;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
@@ -1614,6 +1614,7 @@ struct rtmi_ctx
 	int walk_depth = 8;          // same for k_trace and k_tail: the larger need of the pairs and of the 4-wide nodes; sizes the suspend records
 	hipStream_t side = 0;        // a bounce's shadow walk runs here, beside the next bounce's closest-hit walk on the main stream (RTMI_OVERLAP=0: on the main stream)
 	bool overlap_on = true;
+	bool plane_pairs_on = true;  // option plane_pairs = 0: the generic plane loop even for the reference's room (isect_planes); takes effect at the next upload
 	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
 	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
@@ -2044,7 +2045,7 @@ static void set_max_blocks( rtmi_ctx* c )
 static int set_lanes( rtmi_ctx* c );
 struct OptDesc { const char* key; long long lo, hi; };
 static const OptDesc g_opts[] = {
-	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "carry", 0, 1 }, { "tail_lanes", 1, 64 }, { "tail_waves", 1, 32 }, { "sblock", 256, 1024 },
+	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "plane_pairs", 0, 1 }, { "carry", 0, 1 }, { "tail_lanes", 1, 64 }, { "tail_waves", 1, 32 }, { "sblock", 256, 1024 },
 	{ "tail_block", 1, 16 }, { "tail_dense", 0, 1ll << 32 }, { "tail_mid", 0, 1ll << 32 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
 	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
@@ -2062,6 +2063,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	if (is( "log_bounces" )) c->log_bounces = v != 0;
 	else if (is( "overlap" )) c->overlap_on = v != 0 && c->side != 0;
 	else if (is( "wide" )) c->wide_on = v != 0;
+	else if (is( "plane_pairs" )) c->plane_pairs_on = v != 0;
 	else if (is( "carry" )) { c->carry_on = v != 0; if (!c->tail_paths_set) c->tail_paths = c->carry_on ? 1u << 22 : c->small_paths; }
 	else if (is( "tail_lanes" )) { if (v & ( v - 1 )) return fail( c, RTMI_ERR_INVALID, "tail_lanes must be a power of two" ); c->tail_lanes = (int)v; }
 	else if (is( "tail_waves" )) c->tail_waves = (int)v;
@@ -2118,7 +2120,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 {
 	auto is = [&]( const char* k ) { return !strcmp( key, k ); };
 	found = true;
-	if (is( "log_bounces" )) return c->log_bounces; if (is( "overlap" )) return c->overlap_on; if (is( "wide" )) return c->wide_on; if (is( "carry" )) return c->carry_on;
+	if (is( "log_bounces" )) return c->log_bounces; if (is( "overlap" )) return c->overlap_on; if (is( "wide" )) return c->wide_on; if (is( "plane_pairs" )) return c->plane_pairs_on; if (is( "carry" )) return c->carry_on;
 	if (is( "tail_lanes" )) return c->tail_lanes; if (is( "tail_waves" )) return c->tail_waves; if (is( "sblock" )) return c->sblock; if (is( "tail_block" )) return c->tail_block;
 	if (is( "tail_dense" )) return c->tail_dense; if (is( "tail_mid" )) return c->tail_mid; if (is( "slots" )) return c->n_slots; if (is( "tail_paths" )) return c->tail_paths;
 	if (is( "carry_cap" )) return c->carry_cap; if (is( "left_cap" )) return c->left_cap; if (is( "carry_bounce" )) return c->carry_bounce; if (is( "step_budget" )) return c->budget;
@@ -2139,7 +2141,7 @@ static int sync_child( rtmi_ctx* c )
 	rtmi_ctx* k = c->child;
 	if (!k) return RTMI_OK;
 	k->ds = c->ds, k->has_scene = c->has_scene, k->stack_depth = c->stack_depth, k->walk_depth = c->walk_depth;
-	k->overlap_on = c->overlap_on && k->side != 0, k->wide_on = c->wide_on, k->refill = c->refill, k->max_blocks = c->max_blocks;
+	k->overlap_on = c->overlap_on && k->side != 0, k->wide_on = c->wide_on, k->plane_pairs_on = c->plane_pairs_on, k->refill = c->refill, k->max_blocks = c->max_blocks;
 	for (int i = 0; i < 2; i++) k->grid_closest[i] = c->grid_closest[i], k->grid_any[i] = c->grid_any[i];
 	k->cam = c->cam, k->seeds = c->seeds, k->accum = c->accum, k->late = c->late, k->odd = c->odd;
 	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->count_lag = c->count_lag, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
@@ -2616,11 +2618,20 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 		float4* a = 0, *b = 0, *p = 0;
 		if (( r = dev_upload( c, &a, q.data(), q.size(), &allocs ) ) || ( r = dev_upload( c, &b, cu.data(), cu.size(), &allocs ) ) || ( r = dev_upload( c, &p, pl.data(), pl.size(), &allocs ) )) return bail( r );
 		ds.quads = a, ds.cubes = b, ds.planes = p;
+		for (int i = 0; i < 4; i++) ds.quad0[i] = q[i];
+		// the reference's room (scene.h:70-75): +x, -x, +y, -y, +z, -z.  Then one division serves each pair (isect_plane_pair)
+		static const float axes[6][3] = { { 1, 0, 0 }, { -1, 0, 0 }, { 0, 1, 0 }, { 0, -1, 0 }, { 0, 0, 1 }, { 0, 0, -1 } };
+		bool paired = c->plane_pairs_on && d->n_planes == 6;
+		for (int i = 0; i < 6 && paired; i++) paired = pl[i].x == axes[i][0] && pl[i].y == axes[i][1] && pl[i].z == axes[i][2] && std::isfinite( pl[i].w );
+		ds.plane_pairs = paired ? 1 : 0;
+		for (int i = 0; i < 6; i++) ds.pair_d[i] = paired ? pl[i].w : 0.0f;
 	}
 	// shading data: per-primitive materials deduplicated into a table (the reference assigns one Material per object / OBJ file)
 	{
 		std::vector<DMaterial> table;
-		std::vector<uint8_t> ids( (size_t)std::max<long long>( total, 1 ) );
+		// (the device copy of `primitives` carries the material index in its w: hit_attributes reads xyz only, and the planes' d
+		// lives in ds.planes)
+		std::vector<float4> prim_host( (size_t)std::max<long long>( total, 1 ), make_float4( 0, 0, 0, 0 ) );
 		for (long long i = 0; i < total; i++)
 		{
 			DMaterial m = {};
@@ -2634,14 +2645,15 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 				if (table.size() >= 255) return bail( fail( c, RTMI_ERR_INVALID, "more than 255 distinct materials" ) );
 				found = (int)table.size(), table.push_back( m );
 			}
-			ids[i] = (uint8_t)found;
+			memcpy( &prim_host[i], d->primitives + 4 * i, 12 );
+			prim_host[i].w = __builtin_bit_cast( float, (uint32_t)found );
 		}
 		if (table.empty()) table.push_back( DMaterial{} );
-		float4* prim = 0; uint8_t* mid = 0; DMaterial* mt = 0; float* invr = 0; uint32_t* tex = 0;
-		if (( r = dev_upload( c, &prim, (const float4*)d->primitives, (size_t)total, &allocs ) ) || ( r = dev_upload( c, &mid, ids.data(), ids.size(), &allocs ) ) ||
+		float4* prim = 0; DMaterial* mt = 0; float* invr = 0; uint32_t* tex = 0;
+		if (( r = dev_upload( c, &prim, prim_host.data(), prim_host.size(), &allocs ) ) ||
 			( r = dev_upload( c, &mt, table.data(), table.size(), &allocs ) ) || ( r = dev_upload( c, &invr, d->sphere_invr, (size_t)d->n_spheres, &allocs ) )) return bail( r );
 		if (d->texture) { if (( r = dev_upload( c, &tex, d->texture, (size_t)d->tex_w * d->tex_h, &allocs ) )) return bail( r ); }
-		ds.primitives = prim, ds.mat_id = mid, ds.materials = mt, ds.sphere_invr = invr, ds.texture = tex, ds.tex_w = d->tex_w, ds.tex_h = d->tex_h;
+		ds.primitives = prim, ds.materials = mt, ds.sphere_invr = invr, ds.texture = tex, ds.tex_w = d->tex_w, ds.tex_h = d->tex_h;
 	}
 	memcpy( &ds.light_c1, d->light_corners, 16 ), memcpy( &ds.light_c2, d->light_corners + 4, 16 ), memcpy( &ds.light_c3, d->light_corners + 8, 16 );
 	memcpy( &ds.light_emission, d->light_emission, 16 );

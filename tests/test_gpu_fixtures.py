@@ -216,3 +216,41 @@ def test_options_api():
     ref = Oracle(room.desc).sample(32, 32, api.default_camera(32, 32), api.seed_table(32 * 32), 0, 5)
     assert float(np.sqrt(np.mean((acc.astype(np.float64) - ref) ** 2))) <= 5e-5
     d.close()
+
+
+@pytest.mark.parametrize("hook_kernel", [0, 1])
+def test_plane_pairs_equal_the_plane_loop(default_scene, hook_kernel):
+    """The reference's room is three pairs of opposite axis planes; the device tests each pair with one division
+    (rt_device.h isect_plane_pair).  Same hits, same distance bits as the generic plane loop (option plane_pairs = 0)
+    and as the oracle's Plane::Intersect loop (primitive.h:154-158, bvh.h:498-502), for origins inside the room, exactly
+    on a wall, outside it, and for rays with zero direction components."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    O = np.stack([rng.uniform(-3.4, 3.4, n), rng.uniform(-1.4, 2.4, n), rng.uniform(-3.4, 4.4, n)], 1).astype(np.float32)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    O[:3000, 0] = np.float32(-3.0)   # on the plane (1,0,0), d = 3: a = 0
+    O[3000:6000, 1] = np.float32(2.0)  # on (0,-1,0), d = 2
+    O[6000:9000, 2] = np.float32(0.0)
+    D[9000:12000, 0] = 0
+    D[12000:15000, 1] = 0
+    D[15000:16000, 1:] = 0
+    D[16000:17000, 2] = np.float32(-0.0)
+    tmax = np.full(n, 1e34, np.float32)
+    tmax[100000:] = rng.uniform(0.01, 6.0, n - 100000).astype(np.float32)
+    orc = Oracle(default_scene.desc)
+    c_obj, c_t = orc.find_nearest(O, D, tmax)
+    c_occ = orc.is_occluded(O, D, tmax)
+    outside = (np.abs(O[:, 0]) > 3) | (O[:, 1] < -1) | (O[:, 1] > 2)
+    assert 0.2 < outside.mean() < 0.8 and ((c_obj >= 4) & (c_obj < 10)).mean() > 0.3  # both branches are exercised; planes are objects 4..9
+    res = []
+    for pairs in (1, 0):
+        d = api.Device(64, 64, plane_pairs=pairs, hook_kernel=hook_kernel)
+        d.upload(default_scene.desc)
+        obj, t = d.trace_rays(O, D, tmax)
+        occ, _ = d.trace_rays(O, D, tmax, any_hit=True)
+        assert np.array_equal(obj, c_obj) and np.array_equal(bits(t), bits(c_t)), pairs
+        assert np.array_equal(occ, c_occ), pairs
+        res.append((obj, t, occ))
+        d.close()
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(res[0], res[1]))
