@@ -2,7 +2,7 @@
 
 Everything is built in-tree with explicit compiler lines (hipcc cross-compiles gfx950 without a GPU):
 
-  raytracer_amd/librtmi.so        include/rtmi.h over the HIP kernels      (hipcc, -ffp-contract=off)
+  raytracer_amd/librtmi.so        include/rtmi.h: csrc/rt_kernels.hip (hipcc) + csrc/rtmi_host.cpp (g++), -ffp-contract=off
   raytracer_amd/librtmi_host.so   Scene/BVH/Camera/Renderer host mirror    (g++,   -ffp-contract=off, OpenMP)
   oracle/liboracle.so             CPU restatement, the parity checker      (g++,   -ffp-contract=off, OpenMP)
   oracle/_ref/libref_WxH.so       the reference itself, dev container only (oracle/ref_build/build_ref.sh)
@@ -40,11 +40,21 @@ def _hipcc():
 
 
 def build_device(force=False):
-    srcs = [os.path.join(CSRC, "rtmi.hip"), os.path.join(CSRC, "rt_device.h"), os.path.join(ROOT, "include", "rtmi.h")]
-    if not force and not _newer(DEVICE_LIB, srcs):
+    """librtmi.so = rt_kernels.hip (kernels + launchers, hipcc for gfx950) + rtmi_host.cpp (the C ABI and all host-side
+    orchestration, plain C++ compiled by g++ against the HIP runtime API headers)."""
+    kern = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rt_device.h", "rt_shared.h")]
+    host = [os.path.join(CSRC, f) for f in ("rtmi_host.cpp", "rt_shared.h")] + [os.path.join(ROOT, "include", "rtmi.h")]
+    host_obj = os.path.join(CSRC, "rtmi_host.o")
+    if not force and not _newer(DEVICE_LIB, kern + host):
         return DEVICE_LIB
-    _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-          "-Wno-unused-result", "-o", DEVICE_LIB, srcs[0]])
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if force or _newer(host_obj, host):
+        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__",
+              "-I" + os.path.join(rocm, "include"), "-c", "-o", host_obj, host[0]])
+    kern_obj = os.path.join(CSRC, "rt_kernels.o")
+    if force or _newer(kern_obj, kern):
+        _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result", "-c", "-o", kern_obj, kern[0]])
+    _run([_hipcc(), "-fPIC", "-shared", "-o", DEVICE_LIB, kern_obj, host_obj, "-ldl", "-lpthread"])
     return DEVICE_LIB
 
 

@@ -8,14 +8,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rt_shared.h"
 
-#define RT_DONE 0xFFFFFFFFu
-#define RT_LEAF 0x80000000u
-#define RT_LEAF_FIRST_BITS 25
-#define RT_LEAF_FIRST_MASK ( ( 1u << RT_LEAF_FIRST_BITS ) - 1u )
-#define RT_LEAF_MAX_COUNT 64
 
-struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3( float x, float y, float z ) { f3 r; r.x = x, r.y = y, r.z = z; return r; }
 __device__ __forceinline__ f3 mk3( float4 v ) { return mk3( v.x, v.y, v.z ); }
 __device__ __forceinline__ f3 operator+( f3 a, f3 b ) { return mk3( a.x + b.x, a.y + b.y, a.z + b.z ); }
@@ -66,45 +61,6 @@ __device__ __forceinline__ uint32_t sample_seed( uint32_t s0, uint32_t s ) // SU
 	return st ? st : 1u;
 }
 
-// ---- device scene ------------------------------------------------------------------------------------------
-struct DMaterial { float4 color; float4 absorption; float ior; int type; int pad0, pad1; }; // 48 B
-
-struct DScene
-{
-	// BVH: pair p holds the two children of one interior node = two reference nodes (bvh.h:11-16) side by side,
-	// 64-byte aligned.  float4 x4: {Lmin.xyz, Lmax.x} {Lmax.yz, Lref, Lcnt} {Rmin.xyz, Rmax.x} {Rmax.yz, Rref, Rcnt}
-	const float4* __restrict__ pairs;
-	// leaf-ordered primitive records (position k == primitiveIdx[k]), 48 B: triangle {p1, tag 0} {e1, objIdx} {e2, -}
-	// sphere {pos, tag 1} {r2,0,0, objIdx} {-}
-	const float4* __restrict__ prims;
-	// 4-wide interior nodes with quantised boxes over the same leaves (wide_step below; null: not built), the exact box of
-	// every leaf at [2 * first primitive position], and the wide root
-	const float4* __restrict__ wide;
-	const float4* __restrict__ leafbox;
-	float root_min[3], root_max[3];
-	uint32_t root_ref, wide_root;
-	int n_quads, n_spheres, n_cubes, n_planes, n_tris, n_bvh_prims;
-	const float4* __restrict__ quads;   // per quad 4 x float4: invT rows 0..2, {size,0,0,0}
-	const float4* __restrict__ cubes;   // per cube 8 x float4: invM rows 0..2, b0, b1, M rows 0..2
-	const float4* __restrict__ planes;  // (N, d)
-	// shading
-	const float4* __restrict__ primitives; // [total] scene.h:120-181 (xyz); w = index into `materials` (uint bits, set on upload): one gather per hit, not two
-	const DMaterial* __restrict__ materials;
-	const float* __restrict__ sphere_invr;
-	const uint32_t* __restrict__ texture;
-	int tex_w, tex_h;
-	float4 light_c1, light_c2, light_c3, light_emission, light_N;
-	float4 light_u, light_w; // normalize(c1 - c2), normalize(c3 - c2): the same for every sample, computed once on upload with the same operations
-	float light_A, light_s;
-	float4 wl_pos[2], wl_color[2];
-	float wl_intensity;
-	// quads[0] (the only quad the reference tests, scene.h:361) as kernel arguments: invT rows 0..2, {size,0,0,0}
-	float4 quad0[4];
-	// plane_pairs != 0: the scene has exactly the six planes +x, -x, +y, -y, +z, -z in this order (the reference's room,
-	// scene.h:70-75); pair_d[k] = d of plane k.  See isect_planes.
-	int plane_pairs;
-	float pair_d[6];
-};
 
 struct RayHit { float t; int obj; int pos; };
 

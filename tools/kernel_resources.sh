@@ -1,8 +1,8 @@
 #!/bin/bash
 # tools/kernel_resources.sh -- per-kernel VGPR/SGPR/scratch/occupancy as the compiler reports them (no GPU needed)
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-result \
-  -Rpass-analysis=kernel-resource-usage -o /tmp/librtmi_res.so raytracer_amd/csrc/rtmi.hip 2>&1 |
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result -c \
+  -Rpass-analysis=kernel-resource-usage -o /tmp/librtmi_res.o raytracer_amd/csrc/rt_kernels.hip 2>&1 |
 python3 -c '
 import re,sys,subprocess
 cur=None; rows=[]
