@@ -88,7 +88,7 @@ typedef struct rtmi_stats {
 	uint64_t primary_samples;   /* pixel-samples started since rtmi_reset_stats */
 	uint64_t extend_rays;       /* closest-hit rays traversed */
 	uint64_t shadow_rays;       /* any-hit rays traversed */
-	/* the four below are filled only while count_nodes is on (counting instantiation of the kernels), else 0 */
+	/* the four below are filled only while count_nodes is 1 (counting instantiation of the kernels over the reference's pairs), else 0 */
 	uint64_t extend_pairs;      /* 64-byte two-child node records fetched by closest-hit traversal */
 	uint64_t extend_prims;      /* 48-byte leaf primitive records tested by closest-hit traversal */
 	uint64_t shadow_pairs;      /* same for any-hit traversal */
@@ -103,18 +103,20 @@ typedef struct rtmi_stats {
 	double   ms_walk;           /* hipEvent time between consecutive shade launches: a bounce's shadow walk and the next bounce's closest-hit walk
 	                               share the chip in it (profiling mode only); ms_extend / ms_connect each span their own launch and overlap */
 	uint64_t n_walk_windows;
-	/* the end-of-render tail kernels, option "tail_profile" only (else 0).  Summed over the lanes that lead a path, in 100 MHz
-	 * ticks: [0] analytic tests of the next ray, [1] closest-hit walk, [2] shading, [3] shadow ray (analytic + walk); counts:
-	 * [4] path-bounces, [5] node steps, [6] leaf primitive tests; per wave: [7] ticks and [8] shader cycles of the whole
-	 * rounds (their ratio x 100 MHz = the clock the rounds ran at); k_tail_team only, shader cycles of the closest-hit walks:
-	 * [9] waiting for node records, [10] all of their node steps, [11] the number of those steps */
-	uint64_t tail_profile[12];
 	double   ms_drain;          /* host time spent inside the read-back / flush calls waiting for the last paths (always measured) */
 	uint64_t n_drains;
 	double   ms_extend_union;   /* profiling mode: time during which at least one closest-hit walk launch was running.  With one lane
 	                               it equals ms_extend; with option lanes = 2 two launches (one per lane) overlap and each one's
 	                               own duration includes the time it shared the chip with the other */
 	double   ms_walk_union;     /* the same for the walk windows of ms_walk */
+	double   ms_shade_union, ms_connect_union; /* the same for the k_shade and the any-hit walk launches */
+	/* count_nodes = 2 (rtmi_set_profiling): the counting kernels walk the tree the timed kernels walk -- 64-byte 4-wide records with
+	 * quantised boxes, every accepted hit confirmed against the 32-byte exact box of its leaf -- instead of the reference's pairs.
+	 * Rays the 4-wide nodes cannot take (an infinite reciprocal direction component) still count under *_pairs. */
+	uint64_t extend_wide_nodes, extend_confirms, shadow_wide_nodes, shadow_confirms;
+	uint64_t dropped_paths;     /* paths ended by the bounce limit of the last tail round (option last_round_bounces; the reference's
+	                               Sample has no limit and does not return from such a path, renderer.cpp:251): 0 = every path of the
+	                               frames rendered since rtmi_reset_stats ended by itself, the image is exact */
 } rtmi_stats;
 
 /* Replaces Kernel::InitCL + `new Kernel`x6 + the W*H-sized `new Buffer`s of Renderer::Init (renderer.cpp:10-49,
@@ -166,11 +168,14 @@ int rtmi_render( rtmi_ctx*, int mode, int sample_begin, int sample_count, int sa
 int rtmi_trace_primary( rtmi_ctx*, int32_t* prim_id_out, float* t_out );
 int rtmi_trace_rays( rtmi_ctx*, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* prim_id_out, float* t_out );
 
-/* No counterpart in the reference.  rtmi_trace_rays for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same kernels, same results, but the rays
- * are staged in a fixed device array that is part of the library's image (9 MB per GPU, held until the process ends)
- * instead of memory the handle allocates.  At most RTMI_NOALLOC_MAX_RAYS rays per call (more: RTMI_ERR_INVALID).  The array
- * is shared by every call on that GPU: calls that overlap on one GPU race. */
+/* No counterpart in the reference.  rtmi_trace_rays for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, a process that has handed all free HBM to other users): same arguments, same results, but
+ * the rays are staged in a fixed device array that is part of the library's image (9 MB per GPU, held until the process ends)
+ * instead of memory the handle allocates: no hipMalloc / hipFree, in this call or behind it.  It still copies from the caller's
+ * host arrays and waits for the result (hipMemcpyAsync + hipStreamSynchronize), so it is NOT legal under HIP graph capture.
+ * Kernels: option hook_kernel 0 and 2 as in rtmi_trace_rays; hook_kernel = 1 (the render path's queues, which may have to be
+ * allocated) is served by kernel 0 here.  At most RTMI_NOALLOC_MAX_RAYS rays per call (more: RTMI_ERR_INVALID).  The array is
+ * shared by every call on that GPU: calls that overlap on one GPU race. */
 #define RTMI_NOALLOC_MAX_RAYS ( 1 << 18 )
 int rtmi_trace_rays_noalloc( rtmi_ctx*, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* prim_id_out, float* t_out );
 
@@ -202,7 +207,17 @@ int rtmi_flush( rtmi_ctx* );
  * Asynchronous like rtmi_render; rtmi_finalize on the root with frames = total samples completes the frame. */
 int rtmi_reduce_accumulator( rtmi_ctx*, void* rccl_comm, int root );
 
-/* Counters and timing (the reference only prints a frame time, renderer.cpp:635-641). */
+/* Replaces the per-frame re-read of Scene::GetLightPos / GetLightColor / intensity by Scene::DirectIllumination (scene.h:343-358,
+ * 490-515, 562-564): the ImGui panel calls SetLightIntensity / SetLightPos / SetLightColor / SetRoofLightColor every frame
+ * (template.cpp:350-465, scene.h:536-551) and the reference's CPU path sees the new values at its next Trace.  Takes effect at the next
+ * rtmi_render of a Whitted mode; no re-upload of the scene.  pos / color: 2 x float4 (light 0 = the quad's centre, 1 = lightPos). */
+int rtmi_set_whitted_lights( rtmi_ctx*, const float pos[8], const float color[8], float intensity );
+/* Free and total device memory of the handle's GPU as the runtime reports them (hipMemGetInfo): what is left beside this
+ * handle's queues (up to 19 GB per batch slot at 1080p), and the check that a call allocated nothing. */
+int rtmi_memory_info( rtmi_ctx*, uint64_t* free_bytes, uint64_t* total_bytes );
+
+/* Counters and timing (the reference only prints a frame time, renderer.cpp:635-641).  count_nodes: 0 off, 1 = the walks run
+ * their counting instantiation over the reference's pairs (rtmi_stats.*_pairs, *_prims), 2 = over the 4-wide nodes (see rtmi_stats). */
 int rtmi_set_profiling( rtmi_ctx*, int hip_event_timing, int count_nodes );
 int rtmi_get_stats( rtmi_ctx*, rtmi_stats* out );
 int rtmi_reset_stats( rtmi_ctx* );

@@ -93,10 +93,13 @@ class Stats(C.Structure):
                 ("extend_walkers", C.c_uint64), ("shadow_walkers", C.c_uint64),
                 ("suspended", C.c_uint64), ("max_extend_steps", C.c_uint64), ("max_shadow_steps", C.c_uint64),
                 ("ms_walk", C.c_double), ("n_walk_windows", C.c_uint64),
-                ("tail_profile", C.c_uint64 * 12), ("ms_drain", C.c_double), ("n_drains", C.c_uint64), ("ms_extend_union", C.c_double), ("ms_walk_union", C.c_double)]
+                ("ms_drain", C.c_double), ("n_drains", C.c_uint64), ("ms_extend_union", C.c_double), ("ms_walk_union", C.c_double),
+                ("ms_shade_union", C.c_double), ("ms_connect_union", C.c_double),
+                ("extend_wide_nodes", C.c_uint64), ("extend_confirms", C.c_uint64), ("shadow_wide_nodes", C.c_uint64), ("shadow_confirms", C.c_uint64),
+                ("dropped_paths", C.c_uint64)]
 
     def as_dict(self):
-        return {k: (list(getattr(self, k)) if k == "tail_profile" else getattr(self, k)) for k, _ in self._fields_}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class Material(C.Structure):
@@ -127,7 +130,8 @@ def device_lib():
         for name in ("rtmi_create", "rtmi_destroy", "rtmi_set_stream", "rtmi_upload_scene", "rtmi_set_camera", "rtmi_set_seeds", "rtmi_reset_accumulator",
                      "rtmi_set_accumulator", "rtmi_render", "rtmi_trace_primary", "rtmi_trace_rays", "rtmi_finalize", "rtmi_postprocess",
                      "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_flush", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats",
-                     "rtmi_use_own_stream", "rtmi_set_option", "rtmi_get_option", "rtmi_reduce_accumulator", "rtmi_trace_rays_noalloc"):
+                     "rtmi_use_own_stream", "rtmi_set_option", "rtmi_get_option", "rtmi_reduce_accumulator", "rtmi_trace_rays_noalloc",
+                     "rtmi_set_whitted_lights", "rtmi_memory_info"):
             getattr(L, name).restype = C.c_int
         L.rtmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.rtmi_destroy.argtypes = [C.c_void_p]
@@ -154,6 +158,8 @@ def device_lib():
         L.rtmi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
         L.rtmi_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
         L.rtmi_reduce_accumulator.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rtmi_set_whitted_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+        L.rtmi_memory_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _dev = L
     return _dev
 
@@ -180,6 +186,7 @@ def host_lib():
         L.rth_scene_load_obj_mtl.argtypes = L.rth_scene_load_obj.argtypes
         L.rth_scene_load_texture_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
         L.rth_scene_finalize.argtypes = [C.c_void_p, C.c_int]
+        L.rth_scene_set_lights.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rth_scene_desc.argtypes = [C.c_void_p]
         L.rth_scene_desc.restype = C.POINTER(SceneDesc)
         L.rth_scene_info.argtypes = [C.c_void_p, C.c_void_p]
@@ -287,6 +294,11 @@ class HostScene:
     def finalize(self, builder=REFERENCE_SAH):
         self.L.rth_scene_finalize(self.h, builder)
         return self
+
+    def set_lights(self, intensity, pos=None, color=None, roof_color=None):
+        """Scene::SetLightIntensity / SetLightPos / SetLightColor / SetRoofLightColor (scene.h:536-551)"""
+        a = [None if v is None else np.ascontiguousarray(v, np.float32) for v in (pos, color, roof_color)]
+        self.L.rth_scene_set_lights(self.h, float(intensity), *[None if v is None else _ptr(v) for v in a])
 
     @property
     def desc(self):
@@ -471,6 +483,17 @@ class Device:
         h, w = px.shape
         self._chk(self.L.rtmi_postprocess(self.h, _ptr(px), w, h, C.byref(fx)))
         return px
+
+    def set_whitted_lights(self, pos, color, intensity):
+        """the two point lights of the Whitted modes (2 x float4 positions and colours, intensity) without a scene re-upload"""
+        pos, color = np.ascontiguousarray(pos, np.float32).reshape(8), np.ascontiguousarray(color, np.float32).reshape(8)
+        self._chk(self.L.rtmi_set_whitted_lights(self.h, _ptr(pos), _ptr(color), float(intensity)))
+
+    def memory_info(self):
+        """(free, total) bytes of device memory"""
+        f, t = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.rtmi_memory_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def set_profiling(self, events=False, count_nodes=False):
         self._chk(self.L.rtmi_set_profiling(self.h, int(events), int(count_nodes)))

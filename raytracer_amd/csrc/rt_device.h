@@ -221,7 +221,7 @@ __device__ __forceinline__ void slab( float bminx, float bminy, float bminz, flo
 	}
 }
 
-struct TravCount { uint32_t pairs, prims; };
+struct TravCount { uint32_t pairs, prims, wide, confirms; }; // pair records / leaf primitive records / 4-wide records fetched, leaf boxes fetched to confirm a hit
 
 // Ordered (near child first) traversal of the pair array with a per-lane stack in LDS.
 //   stack: this lane's column, entries at stack[level * stride]
@@ -409,14 +409,11 @@ __device__ __forceinline__ bool traverse_wide( const DScene& s, f3 O, f3 D, f3 r
 #define RT_QUAD_ROT3( x ) __builtin_amdgcn_update_dpp( 0, (int)( x ), 0x93, 0xF, 0xF, false )
 #define RT_QUAD_BCAST( x, l ) __builtin_amdgcn_update_dpp( 0, (int)( x ), ( l ) * 0x55, 0xF, 0xF, false ) /* every lane reads lane l of its quad */
 #define RT_MISS_KEY 0xFFFFFFFFu
-// PROBE (diagnostic builds of k_tail_team only): *probe += shader cycles from the issue of the node's loads to their arrival
-template <bool ANY, bool PROBE = false>
-__device__ __forceinline__ uint32_t team_wide_step( const DScene& s, uint32_t cur, int j, f3 O, f3 rD, float t, uint32_t* stack, const int stride, int& sp, unsigned long long* probe = nullptr )
+template <bool ANY>
+__device__ __forceinline__ uint32_t team_wide_step( const DScene& s, uint32_t cur, int j, f3 O, f3 rD, float t, uint32_t* stack, const int stride, int& sp )
 {
-	const unsigned long long c0 = PROBE ? __builtin_readcyclecounter() : 0;
 	const float4 q0 = s.wide[4 * cur], q2 = s.wide[4 * cur + 2], q3 = s.wide[4 * cur + 3];
 	const uint32_t ref = ( (const uint32_t*)s.wide )[16 * cur + 4 + j];
-	if (PROBE) { asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" ); *probe += __builtin_readcyclecounter() - c0; }
 	uint32_t ref_pinned = ref;
 	asm volatile( "" : "+v"( ref_pinned ) ); // keep the child reference's load with the node's other loads: one round trip per step, not two
 	const uint32_t ex = __float_as_uint( q0.w );
@@ -482,17 +479,14 @@ __device__ __forceinline__ void prim_candidates( const DScene& s, int pos, f3 O,
 }
 // The walk over the 4-wide nodes by a team (see traverse_wide for the single-lane form it reproduces).  Every lane of the
 // team passes the same ray, hit and stack column; `j` is the lane's number in its team.  Returns true iff ANY and occluded.
-template <bool ANY, bool PROBE = false>
-__device__ __forceinline__ bool team_traverse_wide( const DScene& s, int j, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride, uint32_t& nSteps, uint32_t& nPrims,
-	unsigned long long* probe = nullptr )
+template <bool ANY>
+__device__ __forceinline__ bool team_traverse_wide( const DScene& s, int j, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride, uint32_t& nSteps, uint32_t& nPrims )
 {
 	uint32_t cur = s.wide_root;
 	int sp = 0;
 	while (true)
 	{
-		const unsigned long long c0 = PROBE ? __builtin_readcyclecounter() : 0;
-		while (!( cur & RT_LEAF )) { cur = team_wide_step<ANY, PROBE>( s, cur, j, O, rD, h.t, stack, stride, sp, probe ); nSteps++; }
-		if (PROBE) probe[1] += __builtin_readcyclecounter() - c0; // all node steps of this descent (probe[0]: their fetch waits)
+		while (!( cur & RT_LEAF )) { cur = team_wide_step<ANY>( s, cur, j, O, rD, h.t, stack, stride, sp ); nSteps++; }
 		if (cur == RT_DONE) break;
 		const int first = (int)( cur & RT_LEAF_FIRST_MASK ), count = (int)( ( cur >> RT_LEAF_FIRST_BITS ) & ( RT_LEAF_MAX_COUNT - 1 ) ) + 1;
 		// the exact box of the leaf: a hit found under quantised boxes counts only if this passes the reference's test (traverse_wide)

@@ -222,7 +222,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	const int refill = a.refill;
 	// interior nodes: the 4-wide quantised records where they were built; rays with an infinite reciprocal direction
 	// component (`inexact`) and the counting pass (which counts the reference's nodes) walk the pairs
-	const bool use_wide = !COUNT && s.wide != nullptr;
+	const bool use_wide = ( !COUNT || a.count_wide ) && s.wide != nullptr;
 	// chunk: large enough that the pool counter is not the bottleneck, small enough that the last chunks balance
 	const uint32_t waves = gridDim.x * ( BLOCK / 64 );
 	uint32_t chunk = n / ( waves * 4u );
@@ -235,7 +235,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	int tail_steps = 0; // steps since this wave ran out of new rays
 	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 ), rD = mk3( 0, 0, 1 );
 	RayHit h; h.t = 0, h.obj = -1, h.pos = -1;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc; tc.pairs = 0, tc.prims = 0, tc.wide = 0, tc.confirms = 0;
 	uint32_t steps = 0, maxSteps = 0, nSusp = 0; // COUNT only (nSusp always)
 	for (;;)
 	{
@@ -372,8 +372,8 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 		{
 			if (use_wide)
 			{
-				if (atNode && !inexact) cur = wide_step<ANY>( s, cur, O, rD, h.t, stack, BLOCK, sp );
-				if (__ballot( atNode && inexact ) != 0) { if (atNode && inexact) cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+				if (atNode && !inexact) { if (COUNT) tc.wide++, steps++; cur = wide_step<ANY>( s, cur, O, rD, h.t, stack, BLOCK, sp ); }
+				if (__ballot( atNode && inexact ) != 0) { if (atNode && inexact) { if (COUNT) tc.pairs++, steps++; cur = interior_step<ANY, true>( s, cur, O, rD, h.t, stack, BLOCK, sp ); } }
 			}
 			else if (__ballot( has && inexact ) != 0)
 			{
@@ -391,6 +391,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 			if (hit && use_wide && !inexact)
 			{
 				// reached through quantised boxes: the hit counts only if the leaf's exact box passes the reference's test
+				if (COUNT) tc.confirms++;
 				const float4 b0 = s.leafbox[2 * first], b1 = s.leafbox[2 * first + 1];
 				float tmn, tmx;
 				slab<false>( b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, O, rD, tmn, tmx );
@@ -405,6 +406,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 	{
 		wave_add64( tc.pairs, ANY ? &ctr->shadow_pairs : &ctr->extend_pairs );
 		wave_add64( tc.prims, ANY ? &ctr->shadow_prims : &ctr->extend_prims );
+		wave_add64( tc.wide, &ctr->wide_nodes[ANY ? 1 : 0] ), wave_add64( tc.confirms, &ctr->confirms[ANY ? 1 : 0] );
 		for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_down( maxSteps, o, 64 ); maxSteps = v > maxSteps ? v : maxSteps; }
 		if (lane == 0 && maxSteps) atomicMax( &ctr->max_steps[ANY ? 1 : 0], maxSteps );
 	}
@@ -620,10 +622,8 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // round holds one long path, and a thousand almost-empty resident waves would starve the next batches' bulk kernels).
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
-template <bool PROF>
 __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t team_below, DevCounters* ctr,
-	int stop_late )
+	uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late )
 {
 	extern __shared__ uint32_t lds_stack[];
 	// per_wave paths per 64-lane wave, on every (64 / per_wave)-th lane.  A wave full of long paths pays for the divergence
@@ -640,8 +640,6 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	const uint32_t mode = ctr->tail_mode; // k_tail_decide's word for this round: the flag is read from host memory once, not by every wave
 	const bool hurry = dense_above != 0 && ( mode & TAIL_WAITING ) != 0;
 	if (team_below && ( mode & 3u ) != 0) return; // this round is k_tail_team's or k_tail_wave's (k_tail_decide; launched right after this kernel)
-	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
 	int per_wave;
 	if (hurry)
 	{
@@ -650,7 +648,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 		per_wave = 1;
 		while ((uint32_t)per_wave < need && per_wave < 64) per_wave *= 2;
 	}
-	else per_wave = n > dense_above ? 64 : ( n > mid_above ? ( min_lanes > 16 ? min_lanes : 16 ) : min_lanes );
+	else per_wave = n > dense_above ? 64 : min_lanes;
 	const uint32_t stride = 64u / (uint32_t)per_wave;
 	// Workgroups of several waves: the waves of this kernel live for milliseconds, and a CU that hosts one serves the
 	// blocks of the next batches' k_shade at about half speed (the old wave wins the issue arbitration; the block's barriers
@@ -660,7 +658,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	if (( blockIdx.x * waves_per_block + wave_in_block ) * (uint32_t)per_wave >= n) return; // wave-uniform
 	uint32_t* stack = lds_stack + wave_in_block * ( lds_words / waves_per_block ) + lane / stride; // one column per active lane
 	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	for (;;)
 	{
 		uint32_t base = 0;
@@ -682,9 +680,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 			{
 				// Scene::FindNearest from scratch (the analytic part stored with the entry is recomputed: same bits)
 				RayHit h;
-				unsigned long long tp = PROF ? wall_clock64() : 0;
 				const bool walk = begin_closest( s, O, D, h );
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[0] += x - tp, tp = x, prof[4]++; }
 				nExt++;
 				if (walk)
 				{
@@ -695,12 +691,10 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 					else if (s.wide) traverse_wide<false>( s, O, D, rD, h, stack, per_wave );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
 				}
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x; }
 				Vertex v;
 				const bool late = age == META_AGE_LATE;
 				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v );
 				age = age < META_AGE_LATE ? age + 1 : age;
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[2] += x - tp, tp = x; }
 				if (v.shadow_any)
 				{
 					nSh++;
@@ -718,7 +712,6 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 						if (!occ) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
 				}
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
 				if (!v.push_next) { alive = false; break; }
 				O = v.newO, D = v.newD;
 				// (stop_late: the round of a batch's stragglers -- paths that lag behind their batch because walks of theirs were
@@ -745,11 +738,6 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 	} // next per_wave paths
 	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
-	if (PROF && hurry && n <= 16384u) // the profile covers the regime k_tail_team is for: draining rounds with few paths left
-	{
-		for (int k = 0; k < 5; k++) wave_add64( prof[k], &ctr->tail_prof[k] );
-		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 ), atomicAdd( &ctr->tail_prof[8], __builtin_readcyclecounter() - prof_c0 );
-	}
 }
 
 // Which kernel runs a tail round is decided ONCE per round, here, from the live path count and from whether the host is
@@ -770,9 +758,8 @@ __global__ void k_tail_decide( DevCounters* ctr, const uint32_t* __restrict__ n_
 // tests child j of every 4-wide node and primitive j of every leaf, the rest of the bounce (analytic tests, shading, the
 // random stream) is computed identically by the four lanes, and lane 0 alone writes.  Same visiting order, same
 // arithmetic, same results as k_tail, which stays in charge of every round that is not a draining round with few paths.
-template <bool PROF>
 __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t team_below, uint32_t wave_below, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
 	const uint32_t n = *n_in;
@@ -789,10 +776,8 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 	const int stride = (int)( waves_per_block * 16u );
 	uint32_t* stack = lds_stack + wave_in_block * 16u + tm; // one column per team
 	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
-	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, probe[2] = { 0, 0 };
-	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
 	uint32_t nSteps = 0, nPrims = 0, nStepsAny = 0, nPrimsAny = 0;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	for (;;)
 	{
 		uint32_t base = 0;
@@ -813,9 +798,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 			for (int nb = 0; nb < max_bounces; nb++)
 			{
 				RayHit h;
-				unsigned long long tp = PROF ? wall_clock64() : 0;
 				const bool walk = begin_closest( s, O, D, h );
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[0] += x - tp, tp = x, prof[4]++; }
 				if (j == 0) nExt++;
 				if (walk)
 				{
@@ -824,15 +807,13 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 					// rays that the 4-wide nodes cannot take walk the pairs, the four lanes in step (same values to the same column)
 					if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, stride, tc );
-					else if (s.wide) team_traverse_wide<false, PROF>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims, probe );
+					else if (s.wide) team_traverse_wide<false>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, stride, tc );
 				}
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x; }
 				Vertex v;
 				const bool late = age == META_AGE_LATE;
 				shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v, j == 0 );
 				age = age < META_AGE_LATE ? age + 1 : age;
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[2] += x - tp, tp = x; }
 				if (v.shadow_any)
 				{
 					if (j == 0) nSh++;
@@ -851,7 +832,6 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 						if (!occ && j == 0) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
 				}
-				if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
 				if (!v.push_next) { alive = false; break; }
 				O = v.newO, D = v.newD;
 			}
@@ -876,14 +856,6 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 	} // next per_wave paths
 	wave_add64( nExt, &ctr->extend_rays ), wave_add64( nSh, &ctr->shadow_rays );
 	wave_add64( nExtWalk, &ctr->extend_walkers ), wave_add64( nShWalk, &ctr->shadow_walkers );
-	if (PROF)
-	{
-		prof[5] = nSteps + nStepsAny, prof[6] = nPrims + nPrimsAny;
-		wave_add64( j == 0 ? (unsigned long long)nSteps : 0ull, &ctr->tail_prof[11] );
-		for (int k = 0; k < 7; k++) wave_add64( j == 0 ? prof[k] : 0ull, &ctr->tail_prof[k] );
-		wave_add64( j == 0 ? probe[0] : 0ull, &ctr->tail_prof[9] ), wave_add64( j == 0 ? probe[1] : 0ull, &ctr->tail_prof[10] );
-		if (lane == 0) atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 ), atomicAdd( &ctr->tail_prof[8], __builtin_readcyclecounter() - prof_c0 );
-	}
 }
 
 // ---- the very end of a render: one path per wave ---------------------------------------------------------------------------
@@ -899,7 +871,7 @@ __device__ __forceinline__ void wave_find_nearest( const DScene& s, int lane, f3
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 	if (( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) == RT_DONE) return;
 	walked = true;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	// rays the 4-wide nodes cannot take, and rays whose frontier outgrows the LDS, walk as in k_tail: the 64 lanes in step,
 	// one stack column (the same values to the same addresses)
 	if (inexact) { traverse<false, true, false>( s, O, D, rD, h, L.nref, 1, tc ); return; }
@@ -918,7 +890,7 @@ __device__ __forceinline__ bool wave_is_occluded( const DScene& s, int lane, f3 
 	if (( inexact ? bvh_enter<true>( s, O, rD, tmaxRay ) : bvh_enter<false>( s, O, rD, tmaxRay ) ) == RT_DONE) return false;
 	walked = true;
 	RayHit sh; sh.t = tmaxRay, sh.obj = -1, sh.pos = -1;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	if (inexact) return traverse<true, true, false>( s, O, D, rD, sh, L.nref, 1, tc );
 	if (!s.wide) return traverse<true, false, false>( s, O, D, rD, sh, L.nref, 1, tc );
 	bool overflow;
@@ -926,9 +898,8 @@ __device__ __forceinline__ bool wave_is_occluded( const DScene& s, int lane, f3 
 	return overflow ? traverse_wide<true>( s, O, D, rD, sh, L.nref, 1 ) : occ;
 }
 
-template <bool PROF>
 __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
-	uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t wave_below, DevCounters* ctr )
+	uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
 	__shared__ WaveLds lds[WAVE_WG];
 	const uint32_t n = *n_in;
@@ -937,8 +908,6 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 	WaveLds& L = lds[threadIdx.x >> 6];
 	if (( blockIdx.x * (uint32_t)WAVE_WG + ( threadIdx.x >> 6 ) ) >= n) return; // surplus waves leave at once
 	unsigned long long nExt = 0, nSh = 0, nExtWalk = 0, nShWalk = 0;
-	unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	const unsigned long long prof_t0 = PROF ? wall_clock64() : 0, prof_c0 = PROF ? __builtin_readcyclecounter() : 0;
 	uint32_t nIter = 0, nIterAny = 0;
 	for (;;)
 	{
@@ -955,15 +924,12 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 		{
 			RayHit h;
 			bool walked;
-			unsigned long long tp = PROF ? wall_clock64() : 0;
 			wave_find_nearest( s, lane, O, D, 1e34f, h, L, walked, nIter );
-			if (PROF) { const unsigned long long x = wall_clock64(); prof[1] += x - tp, tp = x, prof[4]++; }
 			nExt++, nExtWalk += walked ? 1 : 0;
 			Vertex v;
 			const bool late = age == META_AGE_LATE;
 			shade_vertex( s, O, D, h.t, h.obj, T, rng, flags, sinks, slot, late, v, lane == 0 );
 			age = age < META_AGE_LATE ? age + 1 : age;
-			if (PROF) { const unsigned long long x = wall_clock64(); prof[2] += x - tp, tp = x; }
 			if (v.shadow_any)
 			{
 				nSh++;
@@ -975,7 +941,6 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 					else add_chain( sinks, slot, late, v.contrib );
 				}
 			}
-			if (PROF) { const unsigned long long x = wall_clock64(); prof[3] += x - tp, tp = x; }
 			if (!v.push_next) { alive = false; break; }
 			O = v.newO, D = v.newD;
 		}
@@ -991,13 +956,6 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 	if (lane == 0)
 	{
 		atomicAdd( &ctr->extend_rays, nExt ), atomicAdd( &ctr->shadow_rays, nSh ), atomicAdd( &ctr->extend_walkers, nExtWalk ), atomicAdd( &ctr->shadow_walkers, nShWalk );
-		if (PROF)
-		{
-			prof[5] = nIter + nIterAny;
-			for (int k = 0; k < 7; k++) if (prof[k]) atomicAdd( &ctr->tail_prof[k], prof[k] );
-			atomicAdd( &ctr->tail_prof[7], wall_clock64() - prof_t0 ), atomicAdd( &ctr->tail_prof[8], __builtin_readcyclecounter() - prof_c0 );
-			atomicAdd( &ctr->tail_prof[11], (unsigned long long)nIter );
-		}
 	}
 }
 
@@ -1034,15 +992,7 @@ __global__ __launch_bounds__( 256 ) void k_rays_wave( DScene s, int n, const flo
 // queue that k_primary has just filled, as entries N, N+1, ...: camera-ray paths and carried paths then bounce together.
 // A carried path keeps its slot (it needs it for its pixel only) and its rng state: its arithmetic is what it would have
 // been in a tail of its own.
-// Veterans: a carried path gets the slot of its pixel in the LAST sample plane a batch can have (k_carry_in; a late path's
-// slot is read modulo W*H only), so a late path whose slot is at or above `veteran_from` when the batch leaves the wavefront
-// loop has already ridden through a batch: it has survived 30+ bounces and is most likely trapped between specular
-// surfaces for hundreds more.  It stays with the batch, whose tail gives it some hundred bounces at once beside the next
-// batches' bulk, instead of 17 per batch as a rider: the fewer such paths are alive when the caller finally waits, the
-// shorter that wait.  (The batch's own paths of that sample plane are taken for veterans too: 1 in S of the newly late
-// paths, a routing matter only.  veteran_from = 0xFFFFFFFF: none.)
-__global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32_t* __restrict__ n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap,
-	uint32_t veteran_from )
+__global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32_t* __restrict__ n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap )
 {
 	__shared__ uint32_t lds_a[16], lds_b[16];
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = *n_in;
@@ -1050,7 +1000,7 @@ __global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32
 	uint32_t meta = 0;
 	const bool valid = i < n;
 	if (valid) ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i], meta = in.meta[i];
-	const bool late = valid && ( ( meta >> META_AGE_SHIFT ) & META_AGE_LATE ) == META_AGE_LATE && !( meta & META_SUSPENDED ) && ( meta & META_SLOT_MASK ) < veteran_from;
+	const bool late = valid && ( ( meta >> META_AGE_SHIFT ) & META_AGE_LATE ) == META_AGE_LATE && !( meta & META_SUSPENDED );
 	uint32_t idx[1];
 	{
 		const bool push[1] = { late };
@@ -1066,8 +1016,7 @@ __global__ __launch_bounds__( 512 ) void k_carry_out( PathState in, const uint32
 	}
 	if (valid && !carried) rest.o_t[idx[0]] = ot, rest.d_h[idx[0]] = dh, rest.T_s[idx[0]] = ts, rest.meta[idx[0]] = meta;
 }
-__global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, const uint32_t* __restrict__ n_carry, uint32_t cap, PathState st, const uint32_t* __restrict__ n_st, uint32_t* __restrict__ wq, DevCounters* ctr,
-	uint32_t WH, uint32_t veteran_from )
+__global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, const uint32_t* __restrict__ n_carry, uint32_t cap, PathState st, const uint32_t* __restrict__ n_st, uint32_t* __restrict__ wq, DevCounters* ctr )
 {
 	__shared__ uint32_t lds[16];
 	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1082,9 +1031,7 @@ __global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, 
 		st.o_t[N + j] = make_float4( O.x, O.y, O.z, h.t );
 		st.d_h[N + j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
 		st.T_s[N + j] = carry.T_s[j];
-		uint32_t meta = carry.meta[j];
-		if (veteran_from != 0xFFFFFFFFu) meta = ( meta & ~META_SLOT_MASK ) | ( ( meta & META_SLOT_MASK ) % WH + veteran_from ); // (every carried path is late)
-		st.meta[N + j] = meta;
+		st.meta[N + j] = carry.meta[j];
 	}
 	const bool push[1] = { walk };
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
@@ -1118,8 +1065,10 @@ __global__ __launch_bounds__( BLOCK ) void k_fold_late( float4* __restrict__ acc
 // end of a bounce: the queue set that was just consumed becomes the output set of the next bounce
 // `report` (may be null): a word of pinned host memory that receives the number of paths + carried shadow rays the next
 // bounce starts with -- written from here instead of a 4-byte copy command per bounce (a copy kernel and its launch gap)
-__global__ void k_next_bounce( DevCounters* ctr, int consumed, uint32_t* report )
+// `drop`: this was the last tail round (launch_tail_rounds): what it left alive has used up its bounces and ends here, counted
+__global__ void k_next_bounce( DevCounters* ctr, int consumed, uint32_t* report, int drop )
 {
+	if (drop) ctr->dropped += ctr->n_state[consumed ^ 1], ctr->n_state[consumed ^ 1] = 0;
 	ctr->n_state[consumed] = 0, ctr->n_walk[consumed] = 0, ctr->n_shadow[consumed] = 0, ctr->pool_extend = 0, ctr->pool_connect = 0, ctr->pool_tail = 0;
 	ctr->n_rec[consumed ^ 1] = 0, ctr->n_srec[consumed ^ 1] = 0; // read by this bounce's walks, written again by the next bounce's
 	const uint32_t pending = ctr->n_state[consumed ^ 1] + ctr->n_shadow[consumed ^ 1];
@@ -1241,7 +1190,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace_rays( DScene s, int n, const 
 	const bool live = i < n;
 	const int k = live ? i : 0;
 	const f3 O = mk3( O3[3 * k], O3[3 * k + 1], O3[3 * k + 2] ), D = mk3( D3[3 * k], D3[3 * k + 1], D3[3 * k + 2] );
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	if (live)
 	{
 		if (any_hit)
@@ -1320,7 +1269,7 @@ __global__ __launch_bounds__( BLOCK ) void k_rays_any_result( const long long* _
 __device__ __forceinline__ f3 direct_illumination( const DScene& s, f3 I, f3 N, uint32_t* stack, int stride ) // scene.h:490-515
 {
 	f3 acc = mk3( 0, 0, 0 );
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	for (int i = 0; i < 2; i++)
 	{
 		const f3 dir = mk3( s.wl_pos[i] ) - I;
@@ -1352,7 +1301,7 @@ __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int
 	const float pat[8] = { -1.0f / 8.0f, 3.0f / 8.0f, 3.0f / 8.0f, 1.0f / 8.0f, -3.0f / 8.0f, -1.0f / 8.0f, 1.0f / 8.0f, -3.0f / 8.0f }; // renderer.h:31-36
 	float4 total = make_float4( 0, 0, 0, 0 );
 	const int nsamp = aa ? 4 : 1;
-	TravCount tc; tc.pairs = 0, tc.prims = 0;
+	TravCount tc = {};
 	for (int smp = 0; smp < nsamp; smp++)
 	{
 		f3 O, D;
@@ -1478,44 +1427,41 @@ void rtk_primary( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene 
 void rtk_trace( bool any, bool count, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr )
 {
 	if (any && count) hipLaunchKernelGGL( ( k_trace<true, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (any) hipLaunchKernelGGL( ( k_trace<true, false> ), grid, block, lds, stream, s, a, ctr );
-	else if (count) hipLaunchKernelGGL( ( k_trace<false, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (true) hipLaunchKernelGGL( ( k_trace<false, false> ), grid, block, lds, stream, s, a, ctr );
+	else if (any && !count) hipLaunchKernelGGL( ( k_trace<true, false> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && count) hipLaunchKernelGGL( ( k_trace<false, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && !count) hipLaunchKernelGGL( ( k_trace<false, false> ), grid, block, lds, stream, s, a, ctr );
 }
 void rtk_shade( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, uint32_t* wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {
 	hipLaunchKernelGGL( k_shade, grid, block, lds, stream, s, in, out, sq, sinks, n_in, n_out, wq_out, n_walk_out, n_shadow, ctr );
 }
-void rtk_tail( bool prof, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t team_below, DevCounters* ctr, int stop_late )
+void rtk_tail( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late )
 {
-	if (prof) hipLaunchKernelGGL( k_tail<true>, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, dense_above, mid_above, min_lanes, lds_words, draining, team_below, ctr, stop_late );
-	else hipLaunchKernelGGL( k_tail<false>, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, dense_above, mid_above, min_lanes, lds_words, draining, team_below, ctr, stop_late );
+	hipLaunchKernelGGL( k_tail, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, dense_above, min_lanes, lds_words, team_below, ctr, stop_late );
 }
 void rtk_tail_decide( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, const uint32_t* n_in, const uint32_t* draining, uint32_t team_below, uint32_t wave_below )
 {
 	hipLaunchKernelGGL( k_tail_decide, grid, block, lds, stream, ctr, n_in, draining, team_below, wave_below );
 }
-void rtk_tail_team( bool prof, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t team_below, uint32_t wave_below, DevCounters* ctr )
+void rtk_tail_team( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
-	if (prof) hipLaunchKernelGGL( k_tail_team<true>, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, draining, team_below, wave_below, ctr );
-	else hipLaunchKernelGGL( k_tail_team<false>, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, draining, team_below, wave_below, ctr );
+	hipLaunchKernelGGL( k_tail_team, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
 }
-void rtk_tail_wave( bool prof, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t wave_below, DevCounters* ctr )
+void rtk_tail_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
-	if (prof) hipLaunchKernelGGL( k_tail_wave<true>, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, draining, wave_below, ctr );
-	else hipLaunchKernelGGL( k_tail_wave<false>, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, draining, wave_below, ctr );
+	hipLaunchKernelGGL( k_tail_wave, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
 }
 void rtk_rays_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out )
 {
 	hipLaunchKernelGGL( k_rays_wave, grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
 }
-void rtk_carry_out( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState in, const uint32_t* n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap, uint32_t veteran_from )
+void rtk_carry_out( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState in, const uint32_t* n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap )
 {
-	hipLaunchKernelGGL( k_carry_out, grid, block, lds, stream, in, n_in, rest, n_rest, carry, n_carry, cap, veteran_from );
+	hipLaunchKernelGGL( k_carry_out, grid, block, lds, stream, in, n_in, rest, n_rest, carry, n_carry, cap );
 }
-void rtk_carry_in( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState carry, const uint32_t* n_carry, uint32_t cap, PathState st, const uint32_t* n_st, uint32_t* wq, DevCounters* ctr, uint32_t WH, uint32_t veteran_from )
+void rtk_carry_in( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState carry, const uint32_t* n_carry, uint32_t cap, PathState st, const uint32_t* n_st, uint32_t* wq, DevCounters* ctr )
 {
-	hipLaunchKernelGGL( k_carry_in, grid, block, lds, stream, s, carry, n_carry, cap, st, n_st, wq, ctr, WH, veteran_from );
+	hipLaunchKernelGGL( k_carry_in, grid, block, lds, stream, s, carry, n_carry, cap, st, n_st, wq, ctr );
 }
 void rtk_carry_commit( dim3 grid, dim3 block, size_t lds, hipStream_t stream, uint32_t* n_st, uint32_t* n_carry, uint32_t cap )
 {
@@ -1525,9 +1471,9 @@ void rtk_fold_late( dim3 grid, dim3 block, size_t lds, hipStream_t stream, float
 {
 	hipLaunchKernelGGL( k_fold_late, grid, block, lds, stream, acc, late, odd, WH );
 }
-void rtk_next_bounce( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed, uint32_t* report )
+void rtk_next_bounce( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed, uint32_t* report, int drop )
 {
-	hipLaunchKernelGGL( k_next_bounce, grid, block, lds, stream, ctr, consumed, report );
+	hipLaunchKernelGGL( k_next_bounce, grid, block, lds, stream, ctr, consumed, report, drop );
 }
 void rtk_next_bounce_pre( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed )
 {

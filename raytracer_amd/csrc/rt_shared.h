@@ -90,7 +90,8 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 	uint32_t pad[1];
 	unsigned long long extend_rays, shadow_rays, extend_pairs, extend_prims, shadow_pairs, shadow_prims, extend_walkers, shadow_walkers, suspended;
 	uint32_t max_steps[2]; // longest single walk (node pairs + leaf records), closest / any; counting instantiation only
-	unsigned long long tail_prof[12]; // option tail_profile: see rtmi_stats.tail_profile
+	unsigned long long wide_nodes[2], confirms[2]; // counting instantiation over the 4-wide nodes (closest / any): 64-byte records fetched, 32-byte leaf boxes fetched to confirm a hit
+	unsigned long long dropped; // paths still alive after the last tail round (option last_round_bounces): ended there
 };
 
 #define FLAG_SPECULAR 1u
@@ -131,6 +132,7 @@ struct TraceArgs
 	uint32_t* n_shadow_out;
 	uint32_t rec_cap;
 	int rec_stride, refill, budget; // budget 0: never suspend
+	int count_wide;                 // counting instantiation: walk (and count) the 4-wide nodes the timed kernel walks instead of the reference's pairs
 };
 
 #define WAVE_WG 8 // waves per k_tail_wave workgroup: an empty round costs the dispatch of its workgroups, so few large ones
@@ -157,16 +159,16 @@ hipError_t rtk_scratch_address( int device, void** out );
 void rtk_primary( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState st, float4* E, float4* Es, uint32_t N, CamProp cam, int W, int H, float invW, float invH, const uint32_t* seeds, int sample_begin, int sample_stride, uint32_t* wq, DevCounters* ctr );
 void rtk_trace( bool any, bool count, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr );
 void rtk_shade( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, uint32_t* wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr );
-void rtk_tail( bool prof, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, uint32_t mid_above, int min_lanes, uint32_t lds_words, const uint32_t* draining, uint32_t team_below, DevCounters* ctr, int stop_late );
+void rtk_tail( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late );
 void rtk_tail_decide( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, const uint32_t* n_in, const uint32_t* draining, uint32_t team_below, uint32_t wave_below );
-void rtk_tail_team( bool prof, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t team_below, uint32_t wave_below, DevCounters* ctr );
-void rtk_tail_wave( bool prof, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, const uint32_t* draining, uint32_t wave_below, DevCounters* ctr );
+void rtk_tail_team( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr );
+void rtk_tail_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr );
 void rtk_rays_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out );
-void rtk_carry_out( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState in, const uint32_t* n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap, uint32_t veteran_from );
-void rtk_carry_in( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState carry, const uint32_t* n_carry, uint32_t cap, PathState st, const uint32_t* n_st, uint32_t* wq, DevCounters* ctr, uint32_t WH, uint32_t veteran_from );
+void rtk_carry_out( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState in, const uint32_t* n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap );
+void rtk_carry_in( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState carry, const uint32_t* n_carry, uint32_t cap, PathState st, const uint32_t* n_st, uint32_t* wq, DevCounters* ctr );
 void rtk_carry_commit( dim3 grid, dim3 block, size_t lds, hipStream_t stream, uint32_t* n_st, uint32_t* n_carry, uint32_t cap );
 void rtk_fold_late( dim3 grid, dim3 block, size_t lds, hipStream_t stream, float4* acc, long long* late, float4* odd, int WH );
-void rtk_next_bounce( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed, uint32_t* report );
+void rtk_next_bounce( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed, uint32_t* report, int drop );
 void rtk_next_bounce_pre( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed );
 void rtk_next_bounce_post( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, int consumed, uint32_t* report );
 void rtk_accumulate( dim3 grid, dim3 block, size_t lds, hipStream_t stream, float4* acc, const float4* E, const long long* Es, int WH, int S );

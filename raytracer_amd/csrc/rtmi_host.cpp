@@ -95,9 +95,9 @@ struct rtmi_ctx
 	bool overlap_on = true;
 	bool plane_pairs_on = true;  // option plane_pairs = 0: the generic plane loop even for the reference's room (isect_planes); takes effect at the next upload
 	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
-	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle
+	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle (8 / 24 / 32: within 1 %)
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
-	uint32_t grid_closest[2] = { 0, 0 }, grid_any[2] = { 0, 0 }; // wgrid; RTMI_GRID_CLOSEST / RTMI_GRID_ANY "a,b" (paths) override, "0,0": always 4 blocks per CU
+	uint32_t grid_closest[2] = { 0, 0 }, grid_any[2] = { 0, 0 }; // wgrid: path counts below which a walk launch keeps 3, then 2 blocks per CU resident (rtmi_create)
 	int n_cus = 256;
 	CamProp cam = {};
 	uint32_t* seeds = 0;
@@ -118,44 +118,37 @@ struct rtmi_ctx
 	bool paths_carried = false;  // some batch since the last join handed paths on (carry buffer, slot lists): the next batch, or join_batches, takes them in
 	uint32_t carry_min = 1u << 22; // option carry_min: a batch of no more camera paths than this finishes its own paths (see render_batch)
 	bool carry_pending = false;  // paths may be waiting in carry[0] / late sums may be non-zero: join_batches finishes them
-	int count_lag = 1;           // option count_lag: bounces after which a small batch's path counts are read (see render_batch)
-	// option small_paths: a batch with no more paths than this leaves the wavefront loop at once.  Renderer::Tick at 1280x720
+	int count_lag = 1;           // bounces after which a small batch's path counts are read (see render_batch)
+	// small_paths: a batch with no more paths than this leaves the wavefront loop at once.  Renderer::Tick at 1280x720
 	// (0.92 M paths per frame): 2^17 5.92 ms, 2^18 5.32, 2^19 4.91, 2^20 4.72 -- below a million paths a wavefront bounce is
 	// launch latency (0.28 ms each) and the tail kernel's 32 bounces in one launch are cheaper; the 20-step bench does not care
 	uint32_t small_paths = 1u << 20;
 	int carry_bounce = 16;       // with carry: the wavefront loop runs at least this many bounces (paths are late from vertex 7; the bounces up to the 16th are large enough to be worth running here)
 	uint32_t tail_paths = 1u << 18; // finish a batch with k_tail once no more than this many paths are alive (0 = never)
 	int tail_lanes = 16;         // fewest paths per wave in the tail rounds after the first (power of two <= 64)
-	int sblock = 512;            // threads per block of k_primary / k_shade (RTMI_SBLOCK): blocks of 16 waves wait for a CU with 4 free
+	int sblock = 512;            // threads per block of k_primary / k_shade: blocks of 16 waves wait for a CU with 4 free
 	                             // slots on every SIMD, which the long-lived tail waves of earlier batches rarely leave
 	int tail_waves = 16;         // resident k_tail waves per CU
-	int tail_block = 4;          // waves per k_tail workgroup (RTMI_TAIL_BLOCK)
-	uint32_t tail_dense = 4096, tail_mid = 0; // k_tail: 64 paths per wave above tail_dense live paths, 16 above tail_mid, else tail_lanes
+	int tail_block = 4;          // waves per k_tail workgroup
+	uint32_t tail_dense = 4096;  // k_tail: 64 paths per wave above tail_dense live paths, else tail_lanes
 	bool log_bounces = false;   // option log_bounces: print the path count per bounce (diagnostics)
 	int budget = 32;            // tail steps after which a still-walking ray is parked (0 = never)
 	int batch_opt = 0;          // option batch: samples per render batch (0 = as many as 2^RTMI_SLOT_BITS paths allow)
 	int fit_samples = 0;        // > 0: the largest batch whose queues were found to fit in device memory (rtmi_render)
-	int blocks_per_cu_opt = 0;  // option blocks_per_cu: resident walk blocks per CU (0 = min(4, what the LDS stack allows))
+	int blocks_per_cu_opt = 0;  // resident walk blocks per CU (0 = min(4, what the LDS stack allows); 3 beside a second lane, set_lanes)
 	bool tail_paths_set = false;
 	bool check_launches = false; // option check_launches: synchronise and check after every bounce (localises a fault; slow)
 	int hook_kernel = 0;        // option hook_kernel: rtmi_trace_rays runs 0 = k_trace_rays (one ray per lane over the reference's pairs),
 	                            // 1 = the render path's own queues and persistent walk (k_trace: 4-wide nodes where built),
 	                            // 2 = the end-of-render walker, one ray per wave (k_rays_wave = k_tail_wave's device code)
-	// option veteran_rounds: -1 (default) = carried paths are carried again; >= 0: they stay with the batch they rode, whose tail
-	// runs this many extra rounds.  Measured (20 bench steps): the final wait falls from 357 ms to 208 ms (2 rounds) / 190 ms (3),
-	// but the tails' waves beside the bulk cost more than that: 126.4 -> 140.5 ms per step.  A trapped path-bounce costs about
-	// 1 ns as a rider of the wavefront kernels and 2-3 ns in a tail kernel, wherever that tail runs.
 	int last_round_bounces = 1 << 16; // see launch_tail_rounds
-	int veteran_rounds = -1;
 	// option preview_reads: rtmi_finalize shows the image as far as it has got instead of finishing every path first -- the frame
 	// loop's display path (Renderer::Tick = one sample and a finalize per frame).  The paths of a frame that are still bouncing
 	// when it is shown (a few thousand of 2 M on the 1 M-triangle scene, inside the mirror and glass knots for thousands of
 	// bounces) ride the next frames' batches; every other read, rtmi_flush and a camera change join as before.
 	bool preview_reads = false;
-	bool stop_late = true;      // option stop_late: a batch's stragglers leave its tail round as soon as they are late (k_tail) instead of after 32 bounces
 	bool tail_team = true;      // option tail_team: draining rounds with no more than team_below live paths run k_tail_team (four lanes per path)
-	bool tail_profile = false;  // option tail_profile: the tail kernels time their phases (rtmi_stats.tail_profile)
-	uint32_t team_below = 1u << 16; // option team_below.  Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds),
+	uint32_t team_below = 1u << 16; // Measured at the end of an 8 x 64-spp render (108 k ... 6 k paths alive over the rounds),
 	                            // before k_tail_wave took more than 4 k paths: k_tail alone 372 ms, teams below 16 k 349, below 64 k 296, below 128 k 281, below 256 k 282
 	bool tail_wave = true;      // option tail_wave: ... and k_tail_wave (one path per wave) at or below wave_below live paths
 	// option wave_below.  The late rounds (1 024 bounces and more) last as long as their longest path: bounces x latency of a bounce,
@@ -171,14 +164,15 @@ struct rtmi_ctx
 	WFrame* frames = 0;
 	int frames_depth = 0;
 	// stats / profiling
-	bool prof_events = false, count_nodes = false;
+	bool prof_events = false; int count_nodes = 0; // count_nodes: 1 = the counting kernels walk the reference's pairs, 2 = the 4-wide nodes the timed kernels walk
 	rtmi_stats stats = {};
 	struct TimedEv { hipEvent_t a, b; int cls; };
 	std::vector<TimedEv> timed;
 	std::vector<hipEvent_t> ev_pool;
 	hipEvent_t prof_base = 0;    // recorded when event timing is switched on: launch intervals are taken relative to it
-	std::vector<std::pair<float, float>> walk_intervals; // the same for the walk windows
-	std::vector<std::pair<float, float>> ext_intervals; // [start, end) of the closest-hit walk launches since rtmi_reset_stats, ms after prof_base
+	// [start, end) of the timed launches since rtmi_reset_stats, ms after prof_base, per class: 0 closest-hit walk, 1 k_shade / k_primary,
+	// 2 any-hit walk, 3 other, 4 the walk windows.  Two lanes' launches of one kernel overlap: the stats give sum and union.
+	std::vector<std::pair<float, float>> intervals[5];
 };
 
 
@@ -237,21 +231,13 @@ static void resolve_timers( rtmi_ctx* c )
 		float ms = 0;
 		if (hipEventSynchronize( t.b ) == hipSuccess && hipEventElapsedTime( &ms, t.a, t.b ) == hipSuccess)
 		{
-			if (t.cls == 0)
-			{
-				c->stats.ms_extend += ms, c->stats.n_extend_launches++;
-				float t0 = 0;
-				if (c->prof_base && hipEventElapsedTime( &t0, c->prof_base, t.a ) == hipSuccess) c->ext_intervals.push_back( { t0, t0 + ms } );
-			}
+			if (t.cls == 0) c->stats.ms_extend += ms, c->stats.n_extend_launches++;
 			else if (t.cls == 1) c->stats.ms_shade += ms, c->stats.n_shade_launches++;
 			else if (t.cls == 2) c->stats.ms_connect += ms, c->stats.n_connect_launches++;
-			else if (t.cls == 4)
-			{
-				c->stats.ms_walk += ms, c->stats.n_walk_windows++;
-				float t0 = 0;
-				if (c->prof_base && hipEventElapsedTime( &t0, c->prof_base, t.a ) == hipSuccess) c->walk_intervals.push_back( { t0, t0 + ms } );
-			}
+			else if (t.cls == 4) c->stats.ms_walk += ms, c->stats.n_walk_windows++;
 			else c->stats.ms_other += ms;
+			float t0 = 0;
+			if (t.cls >= 0 && t.cls <= 4 && t.cls != 3 && c->prof_base && hipEventElapsedTime( &t0, c->prof_base, t.a ) == hipSuccess) c->intervals[t.cls].push_back( { t0, t0 + ms } );
 		}
 		c->ev_pool.push_back( t.a ), c->ev_pool.push_back( t.b );
 	}
@@ -327,31 +313,21 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		// a draining round with few paths left belongs to k_tail_team (the device knows the live count and whether the host waits:
 		// both kernels are launched, the one whose round it is not returns at once)
 		rtk_tail_decide( dim3( 1 ), dim3( 1 ), 0, ts, ctr, &ctr->n_state[cur], c->draining_dev, team_below, wave_below );
-		if (c->tail_profile)
-			rtk_tail( true, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr, stop_late );
-		else
-			rtk_tail( false, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
-				round == 0 ? 0u : c->tail_dense, round == 0 ? 0u : c->tail_mid, c->tail_lanes, lds_words, c->draining_dev, team_below, ctr, stop_late );
+		rtk_tail( dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+			round == 0 ? 0u : c->tail_dense, c->tail_lanes, lds_words, team_below, ctr, stop_late );
 		if (team_below > wave_below)
 		{
 			// (the draining kernels have the chip to themselves: 16 waves per CU whatever tail_waves says about tails beside a bulk)
 			const uint32_t twaves = std::max( 1u, std::min( drain_waves, std::min( upper, team_below ) ) ), tblocks = ( twaves + 3 ) / 4;
 			const size_t tlds = (size_t)c->walk_depth * 64u * sizeof( uint32_t ); // 4 waves x 16 teams, one column each
-			if (c->tail_profile)
-				rtk_tail_team( true, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, wave_below, ctr );
-			else
-				rtk_tail_team( false, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, team_below, wave_below, ctr );
+			rtk_tail_team( dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, ctr );
 		}
 		if (wave_below)
 		{
 			// one wave per path, as many waves as the round can have paths (a wave that finds the pool empty leaves at once)
 			// (the rounds of 4096 bounces and more are for a handful of paths: fewer waves, cheaper to dispatch when they find nothing)
 			const uint32_t wwaves = std::max( 1u, std::min( round >= 7 ? 1024u : drain_waves, std::min( upper, wave_below ) ) ), wblocks = ( wwaves + WAVE_WG - 1 ) / WAVE_WG;
-			if (c->tail_profile)
-				rtk_tail_wave( true, dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, wave_below, ctr );
-			else
-				rtk_tail_wave( false, dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, c->draining_dev, wave_below, ctr );
+			rtk_tail_wave( dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, ctr );
 		}
 		if (c->log_bounces && drain) // diagnostics: the survivors of every draining round (synchronises)
 		{
@@ -360,7 +336,7 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 			(void)hipMemcpy( &left, &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost );
 			fprintf( stderr, "rtmi: drain round %d (%d bounces): %u paths survive\n", round, limit, left );
 		}
-		rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
+		rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0, round == 11 ? 1 : 0 );
 		cur ^= 1;
 	}
 	return cur;
@@ -403,8 +379,12 @@ static int join_batches( rtmi_ctx* c, bool preview = false )
 	{
 		// The late paths that the last batches handed on have no batch to ride with: they get a batch of their own, without
 		// camera rays (S = 0): wavefront bounces while they are many, then k_tail.  One per lane, enqueued side by side.
-		const bool mine = c->carry_on && c->paths_carried && c->slots[c->next_slot].E, kids = k && k->carry_on && k->paths_carried && k->slots[k->next_slot].E;
+		// (a lane whose next slot has no queues -- freed by a resize that failed, never sized -- gets the smallest ones first: its carried
+		// paths are finished by this call or the call fails, they are never silently left out of the image)
+		const bool mine = c->carry_on && c->paths_carried, kids = k && k->carry_on && k->paths_carried;
 		int rk = RTMI_OK, r = RTMI_OK;
+		if (mine && !c->slots[c->next_slot].E && ( r = ensure_batch( c, c->slots[c->next_slot], 1 ) )) return r;
+		if (kids && !k->slots[k->next_slot].E && ( rk = ensure_batch( k, k->slots[k->next_slot], 1 ) )) { c->err = k->err; return rk; }
 		uint64_t t0;
 		{ std::lock_guard<std::mutex> lock( c->chain->m ); t0 = c->chain->next_ticket; c->chain->next_ticket += ( mine ? 1 : 0 ) + ( kids ? 1 : 0 ); }
 		std::thread th;
@@ -500,12 +480,9 @@ static void set_max_blocks( rtmi_ctx* c )
 static int set_lanes( rtmi_ctx* c );
 struct OptDesc { const char* key; long long lo, hi; };
 static const OptDesc g_opts[] = {
-	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "plane_pairs", 0, 1 }, { "carry", 0, 1 }, { "tail_lanes", 1, 64 }, { "tail_waves", 1, 32 }, { "sblock", 256, 1024 },
-	{ "tail_block", 1, 16 }, { "tail_dense", 0, 1ll << 32 }, { "tail_mid", 0, 1ll << 32 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
-	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "carry_bounce", 0, 1 << 20 }, { "step_budget", 0, 1 << 20 }, { "refill", 1, 64 },
-	{ "batch", 0, 1 << 20 }, { "blocks_per_cu", 0, 8 }, { "grid_closest_hi", 0, 1ll << 32 }, { "grid_closest_lo", 0, 1ll << 32 }, { "grid_any_hi", 0, 1ll << 32 },
-	{ "grid_any_lo", 0, 1ll << 32 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 }, { "tail_profile", 0, 1 }, { "team_below", 0, 1 << 18 },
-	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "veteran_rounds", -1, 10 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "last_round_bounces", 0, 1 << 30 }, { "stop_late", 0, 1 }, { "small_paths", 1024, 1 << 22 }, { "count_lag", 1, 2 }, { "preview_reads", 0, 1 },
+	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "plane_pairs", 0, 1 }, { "carry", 0, 1 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
+	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "batch", 0, 1 << 20 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 },
+	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "last_round_bounces", 0, 1 << 30 }, { "preview_reads", 0, 1 },
 };
 // `live`: the handle is in use (buffers exist, work may be in flight): wait, then resize what the option sizes
 static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
@@ -520,37 +497,24 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "wide" )) c->wide_on = v != 0;
 	else if (is( "plane_pairs" )) c->plane_pairs_on = v != 0;
 	else if (is( "carry" )) { c->carry_on = v != 0; if (!c->tail_paths_set) c->tail_paths = c->carry_on ? 1u << 22 : c->small_paths; }
-	else if (is( "tail_lanes" )) { if (v & ( v - 1 )) return fail( c, RTMI_ERR_INVALID, "tail_lanes must be a power of two" ); c->tail_lanes = (int)v; }
-	else if (is( "tail_waves" )) c->tail_waves = (int)v;
-	else if (is( "sblock" )) { if (v != 256 && v != 512 && v != 1024) return fail( c, RTMI_ERR_INVALID, "sblock must be 256, 512 or 1024" ); c->sblock = (int)v; }
-	else if (is( "tail_block" )) c->tail_block = (int)v;
-	else if (is( "tail_dense" )) c->tail_dense = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
-	else if (is( "tail_mid" )) c->tail_mid = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
 	else if (is( "tail_paths" )) c->tail_paths = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll ), c->tail_paths_set = true;
-	else if (is( "carry_bounce" )) c->carry_bounce = (int)v;
-	else if (is( "step_budget" )) c->budget = (int)v;
-	else if (is( "refill" )) c->refill = (int)v;
 	else if (is( "batch" )) c->batch_opt = (int)v;
-	else if (is( "grid_closest_hi" )) c->grid_closest[0] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
-	else if (is( "grid_closest_lo" )) c->grid_closest[1] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
-	else if (is( "grid_any_hi" )) c->grid_any[0] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
-	else if (is( "grid_any_lo" )) c->grid_any[1] = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll );
 	else if (is( "check_launches" )) c->check_launches = v != 0;
 	else if (is( "hook_kernel" )) c->hook_kernel = (int)v;
 	else if (is( "tail_team" )) c->tail_team = v != 0;
-	else if (is( "tail_profile" )) c->tail_profile = v != 0;
-	else if (is( "team_below" )) c->team_below = (uint32_t)v;
 	else if (is( "tail_wave" )) c->tail_wave = v != 0;
 	else if (is( "wave_below" )) c->wave_below = (uint32_t)v;
-	else if (is( "veteran_rounds" )) c->veteran_rounds = (int)v;
 	else if (is( "carry_min" )) c->carry_min = (uint32_t)v;
-	else if (is( "small_paths" )) c->small_paths = (uint32_t)v;
-	else if (is( "count_lag" )) c->count_lag = (int)v;
-	else if (is( "stop_late" )) c->stop_late = v != 0;
 	else if (is( "preview_reads" )) c->preview_reads = v != 0;
 	else if (is( "last_round_bounces" )) c->last_round_bounces = (int)v;
-	else if (is( "lanes" )) { c->lanes = (int)v; if (live) { int r = set_lanes( c ); if (r) return r; } }
-	else if (is( "blocks_per_cu" )) { c->blocks_per_cu_opt = (int)v; if (live) set_max_blocks( c ); }
+	else if (is( "lanes" ))
+	{
+		c->lanes = (int)v;
+		// beside another lane's kernels 3 resident walk blocks per CU and 8 tail waves per CU do better than 4 and 16
+		// (20 bench steps: 10 358 -> 10 623 Mrays/s; alone, 4 and 16 are the optimum)
+		c->blocks_per_cu_opt = c->lanes == 2 ? 3 : 0, c->tail_waves = c->lanes == 2 ? 8 : 16;
+		if (live) { set_max_blocks( c ); int r = set_lanes( c ); if (r) return r; }
+	}
 	else if (is( "slots" ))
 	{
 		c->n_slots = (int)v, c->next_slot = 0, c->fit_samples = 0;
@@ -575,15 +539,25 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 {
 	auto is = [&]( const char* k ) { return !strcmp( key, k ); };
 	found = true;
-	if (is( "log_bounces" )) return c->log_bounces; if (is( "overlap" )) return c->overlap_on; if (is( "wide" )) return c->wide_on; if (is( "plane_pairs" )) return c->plane_pairs_on; if (is( "carry" )) return c->carry_on;
-	if (is( "tail_lanes" )) return c->tail_lanes; if (is( "tail_waves" )) return c->tail_waves; if (is( "sblock" )) return c->sblock; if (is( "tail_block" )) return c->tail_block;
-	if (is( "tail_dense" )) return c->tail_dense; if (is( "tail_mid" )) return c->tail_mid; if (is( "slots" )) return c->n_slots; if (is( "tail_paths" )) return c->tail_paths;
-	if (is( "carry_cap" )) return c->carry_cap; if (is( "left_cap" )) return c->left_cap; if (is( "carry_bounce" )) return c->carry_bounce; if (is( "step_budget" )) return c->budget;
-	if (is( "refill" )) return c->refill; if (is( "batch" )) return c->batch_opt; if (is( "blocks_per_cu" )) return c->blocks_per_cu_opt;
-	if (is( "grid_closest_hi" )) return c->grid_closest[0]; if (is( "grid_closest_lo" )) return c->grid_closest[1]; if (is( "grid_any_hi" )) return c->grid_any[0]; if (is( "grid_any_lo" )) return c->grid_any[1];
-	if (is( "check_launches" )) return c->check_launches; if (is( "hook_kernel" )) return c->hook_kernel; if (is( "tail_team" )) return c->tail_team; if (is( "tail_profile" )) return c->tail_profile;
-	if (is( "team_below" )) return c->team_below;
-	if (is( "tail_wave" )) return c->tail_wave; if (is( "wave_below" )) return c->wave_below; if (is( "veteran_rounds" )) return c->veteran_rounds; if (is( "carry_min" )) return c->carry_min; if (is( "lanes" )) return c->lanes; if (is( "last_round_bounces" )) return c->last_round_bounces; if (is( "stop_late" )) return c->stop_late; if (is( "small_paths" )) return c->small_paths; if (is( "count_lag" )) return c->count_lag; if (is( "preview_reads" )) return c->preview_reads;
+	if (is( "log_bounces" )) return c->log_bounces;
+	if (is( "overlap" )) return c->overlap_on;
+	if (is( "wide" )) return c->wide_on;
+	if (is( "plane_pairs" )) return c->plane_pairs_on;
+	if (is( "carry" )) return c->carry_on;
+	if (is( "slots" )) return c->n_slots;
+	if (is( "tail_paths" )) return c->tail_paths;
+	if (is( "carry_cap" )) return c->carry_cap;
+	if (is( "left_cap" )) return c->left_cap;
+	if (is( "batch" )) return c->batch_opt;
+	if (is( "check_launches" )) return c->check_launches;
+	if (is( "hook_kernel" )) return c->hook_kernel;
+	if (is( "tail_team" )) return c->tail_team;
+	if (is( "tail_wave" )) return c->tail_wave;
+	if (is( "wave_below" )) return c->wave_below;
+	if (is( "carry_min" )) return c->carry_min;
+	if (is( "lanes" )) return c->lanes;
+	if (is( "last_round_bounces" )) return c->last_round_bounces;
+	if (is( "preview_reads" )) return c->preview_reads;
 	found = false;
 	return 0;
 }
@@ -600,10 +574,10 @@ static int sync_child( rtmi_ctx* c )
 	for (int i = 0; i < 2; i++) k->grid_closest[i] = c->grid_closest[i], k->grid_any[i] = c->grid_any[i];
 	k->cam = c->cam, k->seeds = c->seeds, k->accum = c->accum, k->late = c->late, k->odd = c->odd;
 	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->count_lag = c->count_lag, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
-	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense, k->tail_mid = c->tail_mid;
+	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense;
 	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
-	k->veteran_rounds = c->veteran_rounds, k->tail_team = c->tail_team, k->tail_profile = c->tail_profile, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
-	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->stop_late = c->stop_late, k->last_round_bounces = c->last_round_bounces, k->preview_reads = c->preview_reads;
+	k->tail_team = c->tail_team, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
+	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->last_round_bounces = c->last_round_bounces, k->preview_reads = c->preview_reads;
 	int r = RTMI_OK;
 	if (k->carry_cap != c->carry_cap) { r = apply_option( k, "carry_cap", c->carry_cap, true ); if (r) return r; }
 	if (k->left_cap != c->left_cap) { r = apply_option( k, "left_cap", c->left_cap, true ); if (r) return r; }
@@ -642,7 +616,7 @@ static void merge_stats( rtmi_stats& a, rtmi_stats& b ) // a += b, b = 0
 	a.n_extend_launches += b.n_extend_launches, a.n_shade_launches += b.n_shade_launches, a.n_connect_launches += b.n_connect_launches, a.n_walk_windows += b.n_walk_windows;
 	a.extend_walkers += b.extend_walkers, a.shadow_walkers += b.shadow_walkers, a.suspended += b.suspended;
 	a.max_extend_steps = std::max( a.max_extend_steps, b.max_extend_steps ), a.max_shadow_steps = std::max( a.max_shadow_steps, b.max_shadow_steps );
-	for (int i = 0; i < 12; i++) a.tail_profile[i] += b.tail_profile[i];
+	a.dropped_paths += b.dropped_paths, a.extend_wide_nodes += b.extend_wide_nodes, a.extend_confirms += b.extend_confirms, a.shadow_wide_nodes += b.shadow_wide_nodes, a.shadow_confirms += b.shadow_confirms;
 	b = rtmi_stats{};
 }
 
@@ -684,16 +658,11 @@ int rtmi_create( rtmi_ctx** out, int device_id, int width, int height )
 			const long long v = *e ? atoll( e ) : 1;
 			if (apply_option( c, o.key, v, false ) != RTMI_OK) fprintf( stderr, "rtmi_create: ignoring %s=%s (%s)\n", name.c_str(), e, c->err.c_str() ), c->err.clear();
 		}
-		// earlier spellings of three of them
-		if (getenv( "RTMI_GRID_CLOSEST" )) sscanf( getenv( "RTMI_GRID_CLOSEST" ), "%u,%u", &c->grid_closest[0], &c->grid_closest[1] );
-		if (getenv( "RTMI_GRID_ANY" )) sscanf( getenv( "RTMI_GRID_ANY" ), "%u,%u", &c->grid_any[0], &c->grid_any[1] );
-		// Two lanes pay only when their streams do not share hardware queues: 2 x (main, side, 4 tails) + the caller's.  HIP gives a
-		// process GPU_MAX_HW_QUEUES of them (4 unless the process raised it before the runtime started): measured at 20 bench
-		// steps, 2 lanes on 16 queues +8.5 % rays/s, on 4 queues -2 %.
-		if (!getenv( "RTMI_LANES" )) { const char* q = getenv( "GPU_MAX_HW_QUEUES" ); c->lanes = q && atoi( q ) >= 12 ? 2 : 1; }
-		// beside another lane's kernels 3 resident walk blocks per CU and 8 tail waves per CU do better than 4 and 16
-		// (20 bench steps: 10 358 -> 10 623 Mrays/s; alone, 4 and 16 are the optimum)
-		if (c->lanes == 2) { if (!getenv( "RTMI_BLOCKS_PER_CU" )) c->blocks_per_cu_opt = 3; if (!getenv( "RTMI_TAIL_WAVES" )) c->tail_waves = 8; }
+		// (One lane unless the caller asks for two -- option lanes, or RTMI_LANES in the environment.  Two lanes pay only when their
+		// streams do not share hardware queues: 2 x (main, side, 4 tails) + the caller's, and HIP gives a process GPU_MAX_HW_QUEUES
+		// of them, 4 unless the process raised it BEFORE the runtime started, which this library cannot see or check: measured at
+		// 20 bench steps, 2 lanes on 16 queues +8.5 % rays/s, on 4 queues -2 %; and a second lane doubles the queue memory.
+		// bench.py sets the variable before it imports torch and asks for two lanes.)
 		if (!getenv( "RTMI_SLOTS" ))
 		{
 			const char* q = getenv( "GPU_MAX_HW_QUEUES" );
@@ -1225,7 +1194,7 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	a.rec_in = any ? b.srec[set ^ 1] : b.rec[set ^ 1], a.rec_out = any ? b.srec[set] : b.rec[set];
 	a.n_rec_out = any ? &ctr->n_srec[set] : &ctr->n_rec[set], a.n_rec_in = any ? &ctr->n_srec[set ^ 1] : &ctr->n_rec[set ^ 1];
 	a.n_shadow_out = &ctr->n_shadow[set ^ 1];
-	a.rec_cap = b.rec_cap, a.rec_stride = b.rec_stride, a.refill = c->refill, a.budget = budget;
+	a.rec_cap = b.rec_cap, a.rec_stride = b.rec_stride, a.refill = c->refill, a.budget = budget, a.count_wide = c->count_nodes == 2;
 	ScopedTimer t( c, any ? 2 : 0, s );
 	if (any)
 	{
@@ -1240,7 +1209,7 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 }
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
 {
-	ScopedTimer t( c, 1, c->stream );
+	ScopedTimer t( c, 3, c->stream ); // (class "other": ms_shade is k_shade alone)
 	rtk_primary( dim3( nsblocks( c, N ) ), dim3( c->sblock ), 0, c->stream, c->ds, b.st[0], b.E, (float4*)b.Es, N, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, // camera.h:31-32
 		c->seeds, sample_begin, stride, b.wq[0], b.ctr );
 }
@@ -1266,16 +1235,13 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 	if (S != 0) launch_primary( c, b, N, sample_begin, stride );
 	c->stats.primary_samples += N;
 	uint32_t upper = N; // upper bound of the current path queue length (lengths never grow)
-	// veterans (k_carry_out): the slots of the last sample plane that fits a batch; needs two planes and the carry
-	const uint32_t planes = (uint32_t)( ( 1ull << RTMI_SLOT_BITS ) / (unsigned)WH );
-	const uint32_t veteran_from = c->carry_on && c->veteran_rounds >= 0 && planes >= 2 ? ( planes - 1 ) * (uint32_t)WH : 0xFFFFFFFFu;
 	if (c->carry_on && c->paths_carried)
 	{
 		// the late paths that earlier batches handed on bounce along with this batch's (entries N, N+1, ...): the carry buffer
 		// (the previous batch's), and what outlived the first tail round of the batch that used this slot before -- of all
 		// slots when this is the last batch
 		auto take = [&]( PathState src, uint32_t* n_src, uint32_t cap ) {
-			rtk_carry_in( dim3( ( cap + 511 ) / 512 ), dim3( 512 ), 0, s, c->ds, src, n_src, cap, b.st[0], &ctr->n_state[0], b.wq[0], ctr, (uint32_t)WH, veteran_from );
+			rtk_carry_in( dim3( ( cap + 511 ) / 512 ), dim3( 512 ), 0, s, c->ds, src, n_src, cap, b.st[0], &ctr->n_state[0], b.wq[0], ctr );
 			rtk_carry_commit( dim3( 1 ), dim3( 1 ), 0, s, &ctr->n_state[0], n_src, cap );
 			upper += cap; };
 		take( c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap );
@@ -1337,7 +1303,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		else
 		{
 			launch_trace( c, b, true, cur, upper, budget ); // this bounce's shadow rays (at most `upper` + the carried ones)
-			rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, b.host_counts_dev + slot );
+			rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, b.host_counts_dev + slot, 0 );
 			HIPCHK( hipEventRecord( b.count_ev[slot], s ) );
 		}
 		c->stats.bounce_launches++;
@@ -1368,7 +1334,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 		c->paths_carried = true;
 		// late paths -> carry buffer (they join the next batch, or join_batches finishes them); the others -> the other state set
 		rtk_carry_out( dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, s, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1],
-			c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap, veteran_from );
+			c->carry[0], &c->carry_ctr->n_state[0], c->carry_cap );
 		if (c->log_bounces)
 		{
 			uint32_t rest = 0, carried = 0;
@@ -1376,7 +1342,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			(void)hipMemcpy( &rest, &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost ), (void)hipMemcpy( &carried, &c->carry_ctr->n_state[0], 4, hipMemcpyDeviceToHost );
 			fprintf( stderr, "rtmi: hand-over after %d bounces: %u paths carried on (buffer %u), %u stay for this batch's tail\n", (int)c->stats.bounce_launches, carried, c->carry_cap, rest );
 		}
-		rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, (uint32_t*)0 );
+		rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, s, ctr, cur, (uint32_t*)0, 0 );
 		cur ^= 1;
 	}
 	c->carry_pending = true; // also without carry: late sums wait to be folded
@@ -1392,13 +1358,12 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			// what stays with the batch are the paths that were not late yet (parked walks make a path lag): after the 32 bounces
 			// of the first round the survivors are, and wait in the slot's list for the next batch that uses the slot; only
 			// what does not fit goes through the remaining rounds
-			// (with veterans: `veteran_rounds` more rounds -- 64, 128, ... bounces -- before the survivors go to the list)
-			const int first_rounds = veteran_from != 0xFFFFFFFFu ? std::min( c->veteran_rounds, 10 ) : 0;
-			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, first_rounds, false, first_rounds == 0 && c->stop_late ? 1 : 0 );
-			rtk_carry_out( dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, ts, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1], b.left, b.n_left, c->left_cap, 0xFFFFFFFFu );
-			rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0 );
+			// (a path leaves that round as soon as it is late: k_tail, stop_late)
+			cur = launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 0, false, 1 );
+			rtk_carry_out( dim3( ( upper + 511 ) / 512 ), dim3( 512 ), 0, ts, b.st[cur], &ctr->n_state[cur], b.st[cur ^ 1], &ctr->n_state[cur ^ 1], b.left, b.n_left, c->left_cap );
+			rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0, 0 );
 			cur ^= 1;
-			launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), 4096, first_rounds + 1, 11 ); // normally nothing: a small persistent grid
+			launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), 4096, 1, 11 ); // normally nothing: a small persistent grid
 		}
 		else launch_tail_rounds( c, ts, b.st, cur, ctr, make_sinks( c, b ), upper, 0, 11, last );
 		c->stats.bounce_launches++;
@@ -1426,10 +1391,11 @@ static int fetch_counters( rtmi_ctx* c )
 		if (( r = fetch_counters( c->child ) )) { c->err = c->child->err; return r; }
 		resolve_timers( c->child );
 		merge_stats( c->stats, c->child->stats );
-		c->ext_intervals.insert( c->ext_intervals.end(), c->child->ext_intervals.begin(), c->child->ext_intervals.end() );
-		c->child->ext_intervals.clear();
-		c->walk_intervals.insert( c->walk_intervals.end(), c->child->walk_intervals.begin(), c->child->walk_intervals.end() );
-		c->child->walk_intervals.clear();
+		for (int k = 0; k < 5; k++)
+		{
+			c->intervals[k].insert( c->intervals[k].end(), c->child->intervals[k].begin(), c->child->intervals[k].end() );
+			c->child->intervals[k].clear();
+		}
 	}
 	for (int k = 0; k <= MAX_SLOTS; k++)
 	{
@@ -1442,7 +1408,7 @@ static int fetch_counters( rtmi_ctx* c )
 		c->stats.shadow_pairs += h.shadow_pairs, c->stats.shadow_prims += h.shadow_prims;
 		c->stats.extend_walkers += h.extend_walkers, c->stats.shadow_walkers += h.shadow_walkers, c->stats.suspended += h.suspended;
 		c->stats.max_extend_steps = std::max<uint64_t>( c->stats.max_extend_steps, h.max_steps[0] ), c->stats.max_shadow_steps = std::max<uint64_t>( c->stats.max_shadow_steps, h.max_steps[1] );
-		for (int i = 0; i < 12; i++) c->stats.tail_profile[i] += h.tail_prof[i];
+		c->stats.dropped_paths += h.dropped, c->stats.extend_wide_nodes += h.wide_nodes[0], c->stats.shadow_wide_nodes += h.wide_nodes[1], c->stats.extend_confirms += h.confirms[0], c->stats.shadow_confirms += h.confirms[1];
 		// the ray counters only: the queue lengths of the carry buffer stay
 		HIPCHK( hipMemset( (char*)src + offsetof( DevCounters, extend_rays ), 0, sizeof( DevCounters ) - offsetof( DevCounters, extend_rays ) ) );
 	}
@@ -1807,6 +1773,25 @@ int rtmi_reduce_accumulator( rtmi_ctx* c, void* comm, int root )
 	return RTMI_OK;
 }
 
+int rtmi_set_whitted_lights( rtmi_ctx* c, const float pos[8], const float color[8], float intensity )
+{
+	if (!c || !pos || !color) return RTMI_ERR_INVALID;
+	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_set_whitted_lights before rtmi_upload_scene" );
+	// the scene descriptor travels to k_whitted as a kernel argument: the next launch takes the new values, launches in flight keep theirs
+	memcpy( c->ds.wl_pos, pos, 32 ), memcpy( c->ds.wl_color, color, 32 );
+	c->ds.wl_intensity = intensity;
+	return RTMI_OK;
+}
+int rtmi_memory_info( rtmi_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes )
+{
+	if (!c || !free_bytes || !total_bytes) return RTMI_ERR_INVALID;
+	HIPCHK( hipSetDevice( c->device ) );
+	size_t f = 0, t = 0;
+	HIPCHK( hipMemGetInfo( &f, &t ) );
+	*free_bytes = f, *total_bytes = t;
+	return RTMI_OK;
+}
+
 int rtmi_set_profiling( rtmi_ctx* c, int ev, int cn )
 {
 	if (!c) return RTMI_ERR_INVALID;
@@ -1816,7 +1801,7 @@ int rtmi_set_profiling( rtmi_ctx* c, int ev, int cn )
 		if (!c->prof_base && hipEventCreate( &c->prof_base ) != hipSuccess) c->prof_base = 0;
 		if (c->prof_base) { HIPCHK( hipEventRecord( c->prof_base, c->stream ) ); HIPCHK( hipEventSynchronize( c->prof_base ) ); }
 	}
-	c->prof_events = ev != 0, c->count_nodes = cn != 0;
+	c->prof_events = ev != 0, c->count_nodes = cn < 0 ? 0 : cn > 2 ? 2 : cn;
 	return RTMI_OK;
 }
 // the length of the union of the closest-hit walk launches' intervals (they overlap when two lanes render side by side)
@@ -1838,7 +1823,8 @@ int rtmi_get_stats( rtmi_ctx* c, rtmi_stats* out )
 	int r = fetch_counters( c );
 	if (r) return r;
 	resolve_timers( c );
-	c->stats.ms_extend_union = union_ms( c->ext_intervals ), c->stats.ms_walk_union = union_ms( c->walk_intervals );
+	c->stats.ms_extend_union = union_ms( c->intervals[0] ), c->stats.ms_shade_union = union_ms( c->intervals[1] ), c->stats.ms_connect_union = union_ms( c->intervals[2] ),
+		c->stats.ms_walk_union = union_ms( c->intervals[4] );
 	*out = c->stats;
 	return RTMI_OK;
 }
@@ -1850,7 +1836,7 @@ int rtmi_reset_stats( rtmi_ctx* c )
 	if (r) return r;
 	resolve_timers( c );
 	c->stats = rtmi_stats{};
-	c->ext_intervals.clear(), c->walk_intervals.clear();
+	for (auto& v : c->intervals) v.clear();
 	return RTMI_OK;
 }
 

@@ -52,6 +52,15 @@ int rth_scene_load_obj_mtl( void* s, const char* path, const rth_material* fallb
 	return ( (Scene*)s )->LoadObjectWithMaterials( path, to_mat( fallback ), float3( ox, oy, oz ) ) ? 0 : -1;
 }
 int rth_scene_load_texture_raw( void* s, const char* path, int w, int h ) { return ( (Scene*)s )->LoadTextureRaw( path, w, h ) ? 0 : -1; }
+// Scene::SetLightIntensity / SetLightPos / SetLightColor / SetRoofLightColor (scene.h:536-551)
+void rth_scene_set_lights( void* s, float intensity, const float* pos3, const float* color3, const float* roof3 )
+{
+	Scene* sc = (Scene*)s;
+	sc->SetLightIntensity( intensity );
+	if (pos3) sc->SetLightPos( float3( pos3[0], pos3[1], pos3[2] ) );
+	if (color3) sc->SetLightColor( float3( color3[0], color3[1], color3[2] ) );
+	if (roof3) sc->SetRoofLightColor( float3( roof3[0], roof3[1], roof3[2] ) );
+}
 void rth_scene_finalize( void* s, int builder ) { ( (Scene*)s )->Finalize( (BVH::Builder)builder ); }
 const rtmi_scene_desc* rth_scene_desc( void* s ) { return ( (Scene*)s )->Desc(); }
 void rth_scene_info( void* s, int* out )

@@ -45,6 +45,7 @@ bool Renderer::UploadScene()
 {
 	if (!ctx) { error = "UploadScene before Init"; return false; }
 	if (rtmi_upload_scene( ctx, scene.Desc() ) != RTMI_OK) { error = rtmi_last_error( ctx ); return false; }
+	scene.lightsChanged = false; // (the upload carries the lights)
 	ResetAccumulation();
 	return true;
 }
@@ -80,6 +81,12 @@ void Renderer::Tick( float )
 	if (!scene.isInitialized || !ctx) return; // renderer.cpp:448-449
 	auto t0 = std::chrono::high_resolution_clock::now();
 	int r;
+	if (scene.lightsChanged) // Scene::SetLight* since the last frame (scene.h:536-551)
+	{
+		const rtmi_scene_desc* d = scene.Desc();
+		if (rtmi_set_whitted_lights( ctx, &d->whitted_light_pos[0][0], &d->whitted_light_color[0][0], d->whitted_intensity ) != RTMI_OK) error = rtmi_last_error( ctx );
+		scene.lightsChanged = false;
+	}
 	if (visualizationMode == PathTracing)
 	{
 		// renderer.cpp:524-556: one more frame of samples, then Finalize with f = accumulatedFrames

@@ -310,8 +310,11 @@ bool Scene::LoadObjectImpl( const std::string& file, const Material& material, f
 	// pass 2b: faces -> triangles, in file order
 	const size_t before = vt.size();
 	vt.resize( before + ntri );
+	// (Differences from tinyobj kept on purpose: a face with an index outside the file fails the whole load here -- tinyobj drops that
+	// face with a warning, tiny_obj_loader.h:1497-1503 -- and indices are checked against the file's total vertex count, so a face may
+	// name a vertex that is defined further down; the reference's own assets and the generated meshes do neither.)
 	bool bad = false;
-#pragma omp parallel for schedule( static, 1 ) num_threads( nth )
+#pragma omp parallel for schedule( static, 1 ) num_threads( nth ) reduction( || : bad )
 	for (int k = 0; k < nth; k++)
 	{
 		size_t at = before + ch[k].t0, seenV = ch[k].v0, nextMtl = 0;
@@ -423,12 +426,21 @@ void Scene::Finalize( BVH::Builder builder )
 		const float3 l0 = ( corner1 + corner2 ) * 0.5f - float3( 0, 0.01f, 0 );
 		desc.whitted_light_pos[0][0] = l0.x, desc.whitted_light_pos[0][1] = l0.y, desc.whitted_light_pos[0][2] = l0.z;
 	}
+	MarshalLights();
+	desc.texture = texture.empty() ? 0 : texture.data(), desc.tex_w = tex_w, desc.tex_h = tex_h;
+	isInitialized = true;
+}
+
+// Scene::GetLightPos()[1] / GetLightColor() / intensity (scene.h:343-358, 562-564) into the descriptor.  The reference's setters
+// (scene.h:536-551) are read by DirectIllumination at the next Trace; here Renderer::Tick hands a changed set to the device
+// (rtmi_set_whitted_lights) before the next frame, without a scene upload.
+void Scene::MarshalLights()
+{
 	desc.whitted_light_pos[1][0] = lightPos.x, desc.whitted_light_pos[1][1] = lightPos.y, desc.whitted_light_pos[1][2] = lightPos.z;
 	for (int k = 0; k < 2; k++)
 		desc.whitted_light_color[k][0] = lightColors[k].x, desc.whitted_light_color[k][1] = lightColors[k].y, desc.whitted_light_color[k][2] = lightColors[k].z;
 	desc.whitted_intensity = intensity;
-	desc.texture = texture.empty() ? 0 : texture.data(), desc.tex_w = tex_w, desc.tex_h = tex_h;
-	isInitialized = true;
+	lightsChanged = true;
 }
 
 // (p,q) torus knot centre line c(t) = ((R + r cos qt) cos pt, r sin qt, (R + r cos qt) sin pt), swept by a circle of

@@ -45,10 +45,13 @@ public:
 	const rtmi_scene_desc* Desc() const { return &desc; }
 	int TotalPrimitives() const { return quads_size + spheres_size + cubes_size + planes_size + triangles_size; }
 
-	void SetLightIntensity( float v ) { intensity = v; }
-	void SetLightPos( float3 p ) { lightPos = p; }
-	void SetLightColor( float3 c ) { lightColors[1] = c; }
-	void SetRoofLightColor( float3 c ) { lightColors[0] = c; }
+	// scene.h:536-551 (driven every frame by the UI, template.cpp:350-465): the Whitted point lights.  They reach the device at the
+	// next Renderer::Tick (rtmi_set_whitted_lights), no Finalize / upload needed.
+	void SetLightIntensity( float v ) { intensity = v; MarshalLights(); }
+	void SetLightPos( float3 p ) { lightPos = p; MarshalLights(); }
+	void SetLightColor( float3 c ) { lightColors[1] = c; MarshalLights(); }
+	void SetRoofLightColor( float3 c ) { lightColors[0] = c; MarshalLights(); }
+	bool lightsChanged = false;  // the descriptor's light fields are newer than what the device was last given
 
 	float intensity = 24;                                            // scene.h:562
 	float3 lightPos = float3( -1, 0, 0 );                            // scene.h:563
@@ -76,6 +79,7 @@ public:
 private:
 	bool LoadObjectImpl( const std::string& file, const Material& m, float3 offset, bool useMtl );
 	void InitMaterials();
+	void MarshalLights();
 	std::vector<Quad> vq;
 	std::vector<Sphere> vs;
 	std::vector<Cube> vc;

@@ -200,10 +200,11 @@ def test_options_api():
     d = api.Device(32, 32)
     L = api.device_lib()
     assert L.rtmi_set_option(d.h, b"no_such_option", 1) == -1 and b"unknown option" in L.rtmi_last_error(d.h)
-    assert L.rtmi_set_option(d.h, b"tail_lanes", 3) == -1 and L.rtmi_set_option(d.h, b"slots", 99) == -1
-    assert L.rtmi_set_option(d.h, b"lanes", 3) == -1 and L.rtmi_set_option(d.h, b"count_lag", 0) == -1
-    for key, v in (("wide", 0), ("overlap", 0), ("batch", 3), ("slots", 6), ("carry_cap", 4096), ("left_cap", 64), ("step_budget", 16), ("hook_kernel", 1),
-                   ("carry_min", 0), ("lanes", 2), ("count_lag", 2), ("preview_reads", 1), ("small_paths", 4096), ("wave_below", 64), ("team_below", 256), ("veteran_rounds", 0)):
+    assert L.rtmi_set_option(d.h, b"hook_kernel", 3) == -1 and L.rtmi_set_option(d.h, b"slots", 99) == -1
+    assert L.rtmi_set_option(d.h, b"lanes", 3) == -1 and L.rtmi_set_option(d.h, b"veteran_rounds", 0) == -1  # (an option of round 2, removed)
+    assert d.get_option("lanes") == 1  # one lane unless the caller asks for two
+    for key, v in (("wide", 0), ("overlap", 0), ("batch", 3), ("slots", 6), ("carry_cap", 4096), ("left_cap", 64), ("hook_kernel", 1), ("plane_pairs", 0),
+                   ("carry_min", 0), ("lanes", 2), ("preview_reads", 1), ("wave_below", 64), ("tail_paths", 1000), ("last_round_bounces", 128)):
         d.set_option(key, v)
         assert d.get_option(key) == v
     d.use_own_stream()

@@ -182,8 +182,7 @@ def test_full_size_image_and_properties(full):
     # arithmetic: same bits.  check_launches synchronises per bounce
     for opts in (dict(tail_team=0, tail_wave=0, check_launches=1), dict(tail_team=1, tail_wave=0), dict(tail_team=0, tail_wave=1, wave_below=1 << 16),
                  dict(batch=1, carry_min=0),  # four batches that hand their late paths on, although each is small enough to finish its own (carry_min)
-                 dict(lanes=2, batch=1, carry_min=0),  # two lanes: every other batch is enqueued by a second host thread on a pipeline of its own
-                 dict(veteran_rounds=1, batch=1, carry_min=0)):  # ... and the paths carried twice stay with the batch they rode (k_carry_out)
+                 dict(lanes=2, batch=1, carry_min=0)):  # two lanes: every other batch is enqueued by a second host thread on a pipeline of its own
         d4 = api.Device(W, H, **opts)
         d4.upload(scene.desc)
         d4.set_seeds(seeds)
@@ -288,13 +287,16 @@ def test_a_path_that_never_ends_is_ended(default_scene):
     seeds = api.seed_table(W * H)
     d.set_seeds(seeds)
     d.set_camera(api.default_camera(W, H))
+    d.reset_stats()
     d.render(api.PATHTRACING, 219, 1, 1)
     before = d.accumulator()
+    assert d.stats()["dropped_paths"] == 0  # every path of this frame ended by itself: the image is exact
     d.reset()
     t0 = time.perf_counter()
     d.render(api.PATHTRACING, 220, 1, 1)
     img = d.accumulator()
     assert time.perf_counter() - t0 < 20.0
+    assert d.stats()["dropped_paths"] == 1  # rtmi_stats tells a truncated frame from an exact one
     assert np.isfinite(img).all() and img[..., :3].max() > 0
     ref = Oracle(default_scene.desc).sample(W, H, api.default_camera(W, H), seeds, 219, 1)
     assert rmse(before[..., :3], ref[..., :3]) <= 1e-5
@@ -327,6 +329,79 @@ def test_preview_reads_show_frames_early_and_lose_nothing(full):
     assert np.allclose(got, want, rtol=2e-6, atol=1e-6)
     assert np.array_equal(p.finalize(N), full_px) or (p.finalize(N) == full_px).mean() > 0.9999  # RGB8 truncation can flip on a rounding
     p.close()
+
+
+def test_reset_with_paths_pending_on_both_lanes(full):
+    """rtmi_reset_accumulator drops the paths still riding (carry buffers and slot lists of both lanes) with the image they belonged
+    to: a render after such a reset equals the same render on a fresh handle, bit for bit."""
+    scene, W, H = full[0], 960, 540
+    cam, seeds = api.default_camera(W, H, scene.scale), api.seed_table(W * H)
+    imgs = []
+    for dirty in (True, False):
+        d = api.Device(W, H, lanes=2, batch=2, carry_min=0)
+        d.upload(scene.desc)
+        d.set_seeds(seeds)
+        d.set_camera(cam)
+        if dirty:
+            d.render(api.PATHTRACING, 100, 8, 1)  # four batches, two per lane, their late paths handed on; no read in between
+            d.reset()
+        d.render(api.PATHTRACING, 0, 6, 1)
+        imgs.append(d.accumulator())
+        d.close()
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1])) and imgs[0][..., :3].max() > 0
+
+
+def test_whitted_light_setters_reach_the_device(default_scene):
+    """Scene::SetLightIntensity / SetLightPos / SetLightColor / SetRoofLightColor (scene.h:536-551) between two Whitted frames:
+    the second frame equals the oracle's Trace on the changed descriptor (DirectIllumination, scene.h:490-515), without a scene
+    upload -- through the Renderer surface (Tick hands them on) and through rtmi_set_whitted_lights directly."""
+    W, H = 320, 180
+    r = api.Renderer(W, H, 0)
+    assert r.L.rth_scene_make_default(r.scene.h, api.ASSETS.encode(), api.REFERENCE_SAH) == 0
+    r.init()
+    r.set_mode(api.RAYTRACING)
+    cam = api.default_camera(W, H)
+    r.tick()
+    first = r.accumulator()
+    assert rmse(first[..., :3], Oracle(r.scene.desc).trace(W, H, cam, api.RAYTRACING, 5)[..., :3]) <= 1e-5
+    r.scene.set_lights(11.5, pos=(-1.5, 0.5, 0.25), color=(0.2, 0.9, 0.4), roof_color=(1.0, 0.5, 0.25))
+    r.tick()
+    second = r.accumulator()
+    want = Oracle(r.scene.desc).trace(W, H, cam, api.RAYTRACING, 5)  # the descriptor carries the new lights
+    assert rmse(second[..., :3], want[..., :3]) <= 1e-5 and rmse(second[..., :3], first[..., :3]) > 1e-2
+    # the C ABI entry point on its own
+    d = api.Device(W, H)
+    d.upload(default_scene.desc)
+    d.set_camera(cam)
+    a = r.scene.desc.arrays()
+    d.set_whitted_lights(a["whitted_light_pos"], a["whitted_light_color"], float(a["whitted_intensity"]))
+    d.render(api.RAYTRACING, 0, 1, 1, 5, 0)
+    assert np.array_equal(bits(d.accumulator()), bits(second))
+    d.close()
+
+
+def test_counting_on_the_tree_the_kernels_walk(full):
+    """rtmi_set_profiling(count_nodes = 2): the counting instantiation walks the 4-wide nodes like the timed kernels -- same image,
+    fewer records than pairs, a confirm for at least every hit that was accepted."""
+    scene, W, H = full[0], 480, 270
+    cam, seeds = api.default_camera(W, H, scene.scale), api.seed_table(W * H)
+    out = {}
+    for mode in (0, 1, 2):
+        d = api.Device(W, H)
+        d.upload(scene.desc)
+        d.set_seeds(seeds)
+        d.set_camera(cam)
+        d.set_profiling(False, mode)
+        d.reset_stats()
+        d.render(api.PATHTRACING, 0, 4, 1)
+        out[mode] = (d.accumulator(), d.stats())
+        d.close()
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(bits(out[0][0]), bits(out[2][0]))
+    s1, s2 = out[1][1], out[2][1]
+    assert s1["extend_wide_nodes"] == 0 and s1["extend_pairs"] > 0 and s2["extend_wide_nodes"] > 0
+    assert s2["extend_wide_nodes"] < 0.8 * s1["extend_pairs"] and s2["shadow_wide_nodes"] < 0.8 * s1["shadow_pairs"]
+    assert s2["extend_pairs"] < 0.1 * s1["extend_pairs"]  # only the rays the 4-wide nodes cannot take (the centre row and column of the camera rays)
+    assert 0 < s2["extend_confirms"] <= s2["extend_prims"] and s2["extend_walkers"] == s1["extend_walkers"]
 
 
 def test_two_lanes_counters_and_timing(default_scene):

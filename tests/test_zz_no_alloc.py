@@ -23,7 +23,9 @@ def test_no_alloc_entry_matches_trace_rays(default_scene, gold_small):
         d.set_option("hook_kernel", kernel)
         for any_hit, tm in ((False, far), (True, g["inc_tshadow"])):
             want_obj, want_t = d.trace_rays(O, D, tm, any_hit)
+            free0 = d.memory_info()[0]
             got_obj, got_t = d.trace_rays_noalloc(O, D, tm, any_hit)
+            assert d.memory_info()[0] == free0, "the call changed the amount of free device memory"
             assert np.array_equal(got_obj, want_obj) and np.array_equal(bits(got_t), bits(want_t)), (kernel, any_hit)
             want_obj, want_t = d.trace_rays(O[small], D[small], tm[small], any_hit)
             got_obj, got_t = d.trace_rays_noalloc(O[small], D[small], tm[small], any_hit)
