@@ -341,6 +341,45 @@ def mesh_scene(n_tris_target, builder=BINNED_SAH, materials=None, scale=None, tu
     return s.finalize(builder)
 
 
+def mesh_scene_obj(n_tris_target, cache_dir, builder=BINNED_SAH, tube=0.075):
+    """mesh_scene's scene through the OBJ path the metric names ("path-traced OBJ scene"): each knot is written as a Wavefront OBJ
+    file (rtmi::WriteObj, %.9g: binary32 round trip) unless `cache_dir` already holds it, and loaded with Scene::LoadObject
+    (scene.h:222-291: one Material per file, triangles in file order).  Same triangles, hence the same BVH and the same image bits,
+    as mesh_scene.  Returns (scene, {"obj_write_s", "obj_ingest_s", "bvh_build_s", "obj_bytes"})."""
+    import time
+    L = host_lib()
+    k = mesh_scale(n_tris_target)
+    nv = max(3, int(round((n_tris_target / 6.0 / (KNOT_LENGTH / KNOT_CIRCUMFERENCE)) ** 0.5)))
+    nu = max(8, int(round(n_tris_target / 6.0 / nv)))
+    os.makedirs(cache_dir, exist_ok=True)
+    t_write, paths = 0.0, []
+    for i, x in enumerate((-1.5, 0.0, 1.5)):
+        path = os.path.join(cache_dir, "knot_%dx%d_s%g_t%g_%d.obj" % (nu, nv, k, tube, i))
+        if not os.path.exists(path):
+            t0 = time.time()
+            n = nu * nv * 2
+            v9 = np.zeros((n, 9), np.float32)
+            if L.rth_torus_knot(nu, nv, 0.42 * k, 0.17 * k, tube * k, 2, 3, x * k, 0.0, 1.5 * k, _ptr(v9)) != n:
+                raise RtmiError("torus knot generator")
+            tmp = "%s.tmp%d" % (path, os.getpid())  # (several ranks may start at once: write aside, then rename)
+            if L.rth_write_obj(tmp.encode(), _ptr(v9), n) != 0:
+                raise RtmiError("cannot write " + tmp)
+            os.replace(tmp, path)
+            t_write += time.time() - t0
+        paths.append(path)
+    s = HostScene().make_room(k)
+    s.scale = k
+    s.load_logo()
+    mats = [Material(DIFFUSE, (0.93, 0.21, 0.21)), Material(MIRROR, (0.93, 0.93, 0.93)), Material(GLASS, (0.93, 0.93, 0.93), 1.52)]
+    t0 = time.time()
+    for path, m in zip(paths, mats):
+        s.load_obj(path, m)
+    t_ingest = time.time() - t0
+    t0 = time.time()
+    s.finalize(builder)
+    return s, {"obj_write_s": t_write, "obj_ingest_s": t_ingest, "bvh_build_s": time.time() - t0, "obj_bytes": sum(os.path.getsize(p) for p in paths)}
+
+
 def seed_table(n):
     out = np.zeros(n, np.uint32)
     host_lib().rth_fill_seeds(_ptr(out), n)

@@ -6,7 +6,7 @@ for v in "$@"; do
   python - "$v" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/knob.json")); r = d["roofline"]
-print("%-44s %6.0f Mrays/s %6.1f ms/step drain %4.0f ms | frac %.3f per-launch %.3f | ms %s" % (sys.argv[1], d["value"], d["ms_per_step"], d["drain_ms"], r["frac"], r["per_launch"]["frac"],
+print("%-44s %6.0f Mrays/s %6.1f ms/step drain %4.0f ms | %s frac %.3f | ms %s" % (sys.argv[1], d["value"], d["ms_per_step"], d["drain_ms"], r["kernel"], r["frac"],
       {k[:3]: round(v) for k, v in d["kernel_ms"].items()}), flush=True)
 PY
 done
