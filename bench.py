@@ -107,8 +107,8 @@ class Leg:
         # samples per step over all (virtual) ranks: weak = spp-per-step each, strong = one frame of total-spp
         self.step_spp = a.total_spp if self.strong else a.spp_per_step * self.v_world
         # markers for tools/trace_union.py: two fill kernels that nothing else in the process launches bracket the timed region
-        self.mark_a = torch.zeros(1, dtype=torch.int16, device="cuda")
-        self.mark_b = torch.zeros(1, dtype=torch.int8, device="cuda")
+        self.mark_a = torch.empty(1, dtype=torch.int16, device="cuda")  # (empty: creating them must not launch the marker kernel)
+        self.mark_b = torch.empty(1, dtype=torch.int8, device="cuda")
 
     def step(self, i):
         from raytracer_amd import api, distributed as D

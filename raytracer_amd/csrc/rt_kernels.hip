@@ -36,7 +36,8 @@
 // 1024-thread block (16 waves) reserves its entries with ONE atomic per queue: ballot + mbcnt prefix inside the wave,
 // a 16-entry scan in LDS across waves. ----------------------------------------------------------------------------
 template <int NQ>
-__device__ __forceinline__ void block_append( const bool ( &push )[NQ], uint32_t* const ( &counters )[NQ], uint32_t ( &idx )[NQ], uint32_t* lds /* NQ * 16 */ )
+__device__ __forceinline__ void block_append( const bool ( &push )[NQ], uint32_t* const ( &counters )[NQ], uint32_t ( &idx )[NQ], uint32_t* lds /* NQ * 16 (+ 2 * NQ with `span`) */,
+	uint32_t ( *span )[2] = nullptr /* [NQ][2]: the block's first entry in each queue and how many it appends */ )
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 	uint32_t rank[NQ];
@@ -55,10 +56,16 @@ __device__ __forceinline__ void block_append( const bool ( &push )[NQ], uint32_t
 		for (int w = 0; w < nw; w++) { const uint32_t c = lds[q * 16 + w]; lds[q * 16 + w] = total; total += c; }
 		const uint32_t base = total ? atomicAdd( counters[q], total ) : 0u;
 		for (int w = 0; w < nw; w++) lds[q * 16 + w] += base;
+		if (span) lds[NQ * 16 + 2 * q] = base, lds[NQ * 16 + 2 * q + 1] = total;
 	}
 	__syncthreads();
 #pragma unroll
-	for (int q = 0; q < NQ; q++) idx[q] = lds[q * 16 + wave] + rank[q];
+	for (int q = 0; q < NQ; q++) idx[q] = lds[q * 16 + wave] + rank[q]; // (valid in every lane: the entries reserved by the lanes before it)
+	if (span)
+	{
+#pragma unroll
+		for (int q = 0; q < NQ; q++) span[q][0] = lds[NQ * 16 + 2 * q], span[q][1] = lds[NQ * 16 + 2 * q + 1];
+	}
 }
 __device__ __forceinline__ void wave_add64( unsigned long long v, unsigned long long* dst )
 {
@@ -106,28 +113,38 @@ __device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tm
 __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, float4* __restrict__ E, float4* __restrict__ Es, uint32_t N, CamProp cam, int W, int H, float invW, float invH,
 	const uint32_t* __restrict__ seeds, int sample_begin, int sample_stride, uint32_t* __restrict__ wq, DevCounters* ctr )
 {
-	__shared__ uint32_t lds[16];
+	__shared__ uint32_t lds[16 + 2];
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool walk = false;
+	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 );
+	RayHit h; h.t = 1e34f, h.obj = -1, h.pos = -1;
+	uint32_t seed = 0;
 	if (i < N)
 	{
 		const uint32_t WH = (uint32_t)( W * H ), p = i % WH, sidx = (uint32_t)sample_begin + ( i / WH ) * (uint32_t)sample_stride;
-		f3 O, D;
 		primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
-		RayHit h;
 		walk = begin_closest( s, O, D, h );
-		st.o_t[i] = make_float4( O.x, O.y, O.z, h.t );
-		st.d_h[i] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
-		st.T_s[i] = make_float4( 1, 1, 1, __uint_as_float( sample_seed( seeds[p], sidx ) ) );
-		st.meta[i] = i | ( FLAG_SPECULAR << 30 );
+		seed = sample_seed( seeds[p], sidx );
 		E[i] = make_float4( 0, 0, 0, 0 );
 		Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 ); // 4 x int64 zero
 	}
 	const bool push[1] = { walk };
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
-	uint32_t idx[1];
-	block_append<1>( push, counters, idx, lds );
-	if (walk) wq[idx[0]] = i;
+	uint32_t idx[1], span[1][2];
+	block_append<1>( push, counters, idx, lds, span );
+	if (i < N)
+	{
+		// the block's paths stay in the block's run of entries, the ones that walk the BVH last (as k_shade orders its survivors):
+		// slot i is entry j
+		const uint32_t first = blockIdx.x * blockDim.x, valid = N - first < blockDim.x ? N - first : blockDim.x;
+		const uint32_t walkersBefore = idx[0] - span[0][0], nonWalkers = valid - span[0][1];
+		const uint32_t j = first + ( walk ? nonWalkers + walkersBefore : threadIdx.x - walkersBefore );
+		st.o_t[j] = make_float4( O.x, O.y, O.z, h.t );
+		st.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+		st.T_s[j] = make_float4( 1, 1, 1, __uint_as_float( seed ) );
+		st.meta[j] = i | ( FLAG_SPECULAR << 30 );
+		if (walk) wq[idx[0]] = j;
+	}
 	if (i == 0) ctr->n_state[0] = N;
 }
 
@@ -546,8 +563,8 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, uint32_t* __restrict__ wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {
-	__shared__ uint32_t lds[3 * 16 + 1];
-	if (threadIdx.x == 0) lds[48] = 0;
+	__shared__ uint32_t lds[3 * 16 + 6 + 1];
+	if (threadIdx.x == 0) lds[54] = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n = *n_in;
@@ -589,15 +606,21 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 	}
 	{
 		const unsigned long long m = __ballot( v.shadow_any );
-		if (( threadIdx.x & 63 ) == 0 && m) atomicAdd( &lds[48], (uint32_t)__popcll( m ) );
+		if (( threadIdx.x & 63 ) == 0 && m) atomicAdd( &lds[54], (uint32_t)__popcll( m ) );
 	}
 	const bool push[3] = { v.push_next, walk_next, push_shadow };
 	uint32_t* const counters[3] = { n_out, n_walk_out, n_shadow };
 	uint32_t idx[3];
-	block_append<3>( push, counters, idx, lds );
+	uint32_t span[3][2];
+	block_append<3>( push, counters, idx, lds, span );
 	if (v.push_next)
 	{
-		const uint32_t j = idx[0];
+		// Within the block's run of entries the paths whose next ray walks the BVH come LAST: every hit on a mesh -- the mirror and
+		// glass branches of shade_vertex, the triangle branch of hit_attributes -- belongs to a walker, so the next bounce's waves
+		// over the front of the run take none of those branches, and k_trace finds its rays' state side by side.  (Order inside a
+		// queue has no influence on any path's arithmetic.)
+		const uint32_t before = idx[0] - span[0][0], walkersBefore = idx[1] - span[1][0], nonWalkers = span[0][1] - span[1][1];
+		const uint32_t j = span[0][0] + ( walk_next ? nonWalkers + walkersBefore : before - walkersBefore );
 		out.o_t[j] = make_float4( v.newO.x, v.newO.y, v.newO.z, nh.t );
 		out.d_h[j] = make_float4( v.newD.x, v.newD.y, v.newD.z, __int_as_float( nh.obj ) );
 		out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
@@ -611,7 +634,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 		sq.d_s[si] = make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot | ( late ? SQ_LATE : 0u ) ) );
 		sq.c[si] = make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 );
 	}
-	if (threadIdx.x == 0 && lds[48]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[48] );
+	if (threadIdx.x == 0 && lds[54]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[54] );
 }
 
 // ---- tail: once only a few thousand paths are alive a bounce is pure latency (three launches, each as long as one
@@ -1210,7 +1233,8 @@ __global__ __launch_bounds__( BLOCK ) void k_copy_hits( PathState st, int n, int
 {
 	const int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
-	obj_out[i] = __float_as_int( st.d_h[i].w ), t_out[i] = st.o_t[i].w;
+	const uint32_t p = st.meta[i] & META_SLOT_MASK; // entry i holds the path of slot p (k_primary orders a block's entries; k_rays_begin does not)
+	obj_out[p] = __float_as_int( st.d_h[i].w ), t_out[p] = st.o_t[i].w;
 }
 // The same hook through the render path's own machinery (option hook_kernel = 1): caller rays become entries of a path queue
 // (closest hit) or of a shadow queue (any hit) exactly as k_primary / k_shade would have queued them, and k_trace walks them.
