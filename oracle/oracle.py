@@ -58,6 +58,13 @@ class Oracle:
         self.L.orc_primary_rays(W, H, _p(cam), _p(O), _p(D), _p(rD))
         return O, D, rD
 
+    def set_qbvh(self, on=True):
+        """Scene::SetQBVH: the reference's default 4-wide traversal for every query of this oracle; returns whether it is in use"""
+        return bool(self.L.orc_set_qbvh(self.h, int(on)))
+
+    def qbvh_nodes(self):
+        return int(self.L.orc_qbvh_nodes(self.h))
+
     def primary_hits(self, W, H, cam, mode=0):
         cam, = _f32(cam)
         obj, t = np.zeros(W * H, np.int32), np.zeros(W * H, np.float32)

@@ -249,19 +249,147 @@ struct Oracle
 		return shadow_rec( ray, occluded, 2, c );
 	}
 
+	// ---- the 4-wide QBVH, the reference's default traversal (Scene::useQBVH = true, scene.h:585) -----------------------------------
+	// SIMD_BVH_Node (bvh.h:18-27) with scalars in place of the __m128 unions.  Slots that the reference leaves uninitialised (boxes
+	// and counts of unused children: `new SIMD_BVH_Node[...]`, bvh.h:215) are zero here; the traversal never reads them (it leaves
+	// the node at the first child == -1, bvh.h:611, 727).
+	struct QNode { float bminx[4], bmaxx[4], bminy[4], bmaxy[4], bminz[4], bmaxz[4]; int child[4], count[4]; };
+	std::vector<QNode> qn;
+	bool use_qbvh = false; // Scene::SetQBVH (scene.h:553-556); the contract of this repository is the binary traversal, so off by default
+	void q_set( QNode& q, int slot, const rtmi_bvh_node& n )
+	{
+		q.bminx[slot] = n.aabbMinx, q.bminy[slot] = n.aabbMiny, q.bminz[slot] = n.aabbMinz;
+		q.bmaxx[slot] = n.aabbMaxx, q.bmaxy[slot] = n.aabbMaxy, q.bmaxz[slot] = n.aabbMaxz;
+		q.count[slot] = n.primitiveCount, q.child[slot] = n.leftFirst;
+	}
+	void q_assign( int parentIdx, int childrenIdx ) // BVH::AssignNodeQBVH, bvh.h:177-211
+	{
+		QNode& p = qn[parentIdx];
+		q_set( p, 0, nodes[childrenIdx] ), q_set( p, 1, nodes[childrenIdx + 1] );
+		p.child[2] = -1, p.child[3] = -1;
+	}
+	void q_collapse( int nodeIdx ) // BVH::CollapseBVH, bvh.h:75-174
+	{
+		for (int i = 0; i < 4; i++)
+		{
+			QNode& p = qn[nodeIdx];
+			if (p.child[i] != -1) continue;
+			int greatest_child = -1;
+			float greatest_area = -1.0f;
+			for (int j = 0; j < i; j++) if (p.count[j] == 0)
+			{
+				const float areaX = fabsf( p.bmaxx[j] - p.bminx[j] ), areaY = fabsf( p.bmaxy[j] - p.bminy[j] ), areaZ = fabsf( p.bmaxz[j] - p.bminz[j] );
+				const float area = areaX * areaY + areaY * areaZ + areaZ * areaX;
+				if (area > greatest_area) greatest_area = area, greatest_child = j;
+			}
+			if (greatest_child == -1) break;
+			const int left_child = p.child[greatest_child], right_child = left_child + 1;
+			q_set( p, greatest_child, nodes[left_child] ); // the left child takes its parent's slot,
+			q_set( p, i, nodes[right_child] );             // the right child the first free one
+		}
+		for (int i = 0; i < 4; i++)
+		{
+			if (qn[nodeIdx].child[i] != -1 && qn[nodeIdx].count[i] == 0)
+			{
+				const int newNode = (int)qn.size();
+				qn.push_back( QNode{} ); // (the reference indexes a preallocated array: same numbering)
+				const int childrenIdx = qn[nodeIdx].child[i];
+				qn[nodeIdx].child[i] = newNode;
+				q_assign( newNode, childrenIdx );
+				q_collapse( newNode );
+			}
+		}
+	}
+	// BVH::BuildQBVH, bvh.h:213-249.  Only for an interior primitive root: with a leaf root the reference collapses node 0 itself,
+	// whose plane slot it then takes for an interior node when the scene has no planes: such scenes keep the binary walk.
+	bool build_qbvh()
+	{
+		qn.clear();
+		if (d.n_spheres + d.n_triangles == 0 || nodes[2].primitiveCount > 0) return false;
+		qn.push_back( QNode{} );
+		q_set( qn[0], 0, nodes[1] ), q_set( qn[0], 1, nodes[2] );
+		qn[0].child[2] = qn[0].child[3] = -1;
+		qn.push_back( QNode{} );
+		qn[0].child[1] = 1;
+		q_assign( 1, nodes[2].leftFirst );
+		q_collapse( 1 );
+		return true;
+	}
+	// _mm_min_ps / _mm_max_ps: the SECOND operand whenever the comparison is false, i.e. also when either is NaN
+	static float mn( float a, float b ) { return a < b ? a : b; }
+	static float mx( float a, float b ) { return a > b ? a : b; }
+	unsigned q_aabb( const Ray& ray, const QNode& q, float ray_t ) const // BVH::IntersectAABBSIMD, bvh.h:465-486: one bit per lane
+	{
+		unsigned mask = 0;
+		for (int l = 0; l < 4; l++)
+		{
+			const float tx1 = ( q.bminx[l] - ray.O.x ) * ray.rD.x, tx2 = ( q.bmaxx[l] - ray.O.x ) * ray.rD.x;
+			float tmin = mn( tx1, tx2 ), tmax = mx( tx1, tx2 );
+			const float ty1 = ( q.bminy[l] - ray.O.y ) * ray.rD.y, ty2 = ( q.bmaxy[l] - ray.O.y ) * ray.rD.y;
+			tmin = mx( tmin, mn( ty1, ty2 ) ), tmax = mn( tmax, mx( ty1, ty2 ) );
+			const float tz1 = ( q.bminz[l] - ray.O.z ) * ray.rD.z, tz2 = ( q.bmaxz[l] - ray.O.z ) * ray.rD.z;
+			tmin = mx( tmin, mn( tz1, tz2 ) ), tmax = mn( tmax, mx( tz1, tz2 ) );
+			if (tmax >= tmin && tmin < ray_t && tmax > 0) mask |= 1u << l;
+		}
+		return mask;
+	}
+	void qbvh_rec( Ray& ray, int nodeIdx, float ray_t ) const // BVH::IntersectQBVH(ray, nodeIdx, ...), bvh.h:607-638: ray_t is never refreshed
+	{
+		const QNode& p = qn[nodeIdx];
+		const unsigned intersect = q_aabb( ray, p, ray_t );
+		for (int i = 0; i < 4; i++)
+		{
+			if (p.child[i] == -1) return;
+			if (!( intersect >> i & 1 )) continue;
+			if (p.count[i] > 0) { for (int j = 0; j < p.count[i]; j++) bvh_prim( p.child[i] + j, ray ); }
+			else qbvh_rec( ray, p.child[i], ray_t );
+		}
+	}
+	void intersect_qbvh( Ray& ray ) const // BVH::IntersectQBVH(ray), bvh.h:579-605 (no test of the primitive root's own box)
+	{
+		for (int i = 0; i < d.n_planes; i++) plane( i, ray );
+		qbvh_rec( ray, qn[0].child[1], ray.t );
+	}
+	bool qshadow_rec( Ray& ray, bool isOccluded, int nodeIdx, float ray_t ) const // bvh.h:716-758, statement for statement
+	{
+		if (isOccluded) return isOccluded;
+		const QNode& p = qn[nodeIdx];
+		const unsigned intersect = q_aabb( ray, p, ray_t );
+		bool prevOccluded = false;
+		for (int j = 0; j < 4; j++)
+		{
+			if (p.child[j] == -1) return false;
+			if (!( intersect >> j & 1 )) continue;
+			if (p.count[j] > 0)
+			{
+				for (int i = 0; i < p.count[j]; i++) { bvh_prim( p.child[j] + i, ray ); if (ray.objIdx != -1) return true; }
+			}
+			else prevOccluded = prevOccluded || qshadow_rec( ray, prevOccluded, p.child[j], ray_t );
+		}
+		return prevOccluded;
+	}
+	bool shadow_qbvh( Ray& ray, bool isOccluded ) const // BVH::IntersectQBVHShadowRay, bvh.h:690-714
+	{
+		if (isOccluded) return isOccluded;
+		for (int i = 0; i < d.n_planes; i++) { plane( i, ray ); if (ray.objIdx != -1) return true; }
+		return qshadow_rec( ray, isOccluded, qn[0].child[1], ray.t );
+	}
+
 	// ---- template/scene.h ----
-	void find_nearest( Ray& ray, Counters* c = 0, int mode = 0 ) const // Scene::FindNearest, scene.h:359-368 (useQBVH = false)
+	void find_nearest( Ray& ray, Counters* c = 0, int mode = 0 ) const // Scene::FindNearest, scene.h:359-368
 	{
 		if (c) c->extend++;
 		if (d.n_quads > 0) quad( 0, ray );
 		if (d.n_cubes > 0) cube( 0, ray );
-		if (mode == 1) intersect_bvh_stack( ray ); else intersect_bvh( ray, c );
+		if (( mode == 3 || ( mode == 0 && use_qbvh ) ) && !qn.empty()) intersect_qbvh( ray );
+		else if (mode == 1) intersect_bvh_stack( ray ); else intersect_bvh( ray, c );
 	}
 	bool is_occluded( Ray& ray, Counters* c = 0 ) const // Scene::IsOccluded, scene.h:369-379
 	{
 		if (c) c->shadow++;
 		if (d.n_quads > 0) quad( 0, ray );
 		if (d.n_cubes > 0) cube( 0, ray );
+		if (use_qbvh && !qn.empty()) return shadow_qbvh( ray, ray.objIdx != -1 );
 		return shadow_bvh( ray, ray.objIdx != -1, c );
 	}
 	void brute_force( Ray& ray ) const // every primitive, no BVH: the topology-independent answer
@@ -546,6 +674,16 @@ void* orc_create( const rtmi_scene_desc* d )
 	return o;
 }
 void orc_destroy( void* h ) { delete (Oracle*)h; }
+// Scene::SetQBVH (scene.h:553-556): FindNearest / IsOccluded -- and with them Sample and Trace -- walk the reference's 4-wide QBVH
+// (built on first use).  Returns 1 when the QBVH is in use afterwards (0: off, or a scene whose primitive root is a leaf).
+int orc_set_qbvh( void* h, int on )
+{
+	Oracle* o = (Oracle*)h;
+	if (on && o->qn.empty()) o->build_qbvh();
+	o->use_qbvh = on != 0 && !o->qn.empty();
+	return o->use_qbvh ? 1 : 0;
+}
+int orc_qbvh_nodes( void* h ) { return (int)( (Oracle*)h )->qn.size(); }
 void orc_set_threads( int n ) { omp_set_num_threads( n ); }
 int orc_max_threads() { return omp_get_max_threads(); }
 
@@ -558,7 +696,7 @@ void orc_primary_rays( int W, int H, const float* cam, float* O, float* D, float
 		memcpy( O + 3 * p, &r.O, 12 ), memcpy( D + 3 * p, &r.D, 12 ), memcpy( rD + 3 * p, &r.rD, 12 );
 	}
 }
-// mode 0 = recursive IntersectBVH, 1 = IntersectBVHStack, 2 = brute force over every primitive
+// mode 0 = recursive IntersectBVH (IntersectQBVH after orc_set_qbvh), 1 = IntersectBVHStack, 2 = brute force over every primitive
 void orc_find_nearest( void* h, int mode, int n, const float* O, const float* D, const float* tmax, int* obj, float* t )
 {
 	const Oracle* o = (Oracle*)h;

@@ -57,3 +57,33 @@ def test_trace_depths(pair):
     cam = api.default_camera(320, 180)
     for depth in (1, 3, 8):
         assert same(orc.trace(320, 180, cam, api.RAYTRACING, depth), ref.trace(api.RAYTRACING, depth, qbvh=False)), depth
+
+
+def test_qbvh_default_path_of_the_reference(default_scene):
+    """Scene::useQBVH = true is the reference's default (scene.h:585): the oracle's restatement of BuildQBVH / CollapseBVH /
+    IntersectQBVH / IntersectQBVHShadowRay (bvh.h:75-249, 465-494, 579-638, 690-758) against the reference running them --
+    closest hits, occlusion, a path-traced image and a Whitted image, with zero direction components in the mix (the SSE slab
+    test's NaN behaviour differs from the scalar one)."""
+    ref, orc = R.Ref(320, 180), Oracle(default_scene.desc)
+    assert orc.set_qbvh(True) and orc.qbvh_nodes() == ref.counts["nodes_used_qbvh"]
+    rng = np.random.default_rng(19)
+    n = 40000
+    O = np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1).astype(np.float32)
+    O[:3000] = np.round(O[:3000] * 4) / 4  # origins on coordinates the symmetric meshes have box planes on: 0 * inf = NaN
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    D[:1000, 0] = 0
+    D[1000:2000, 1] = 0
+    D[2000:3000, 2] = 0
+    D[3000:3300, :2] = 0
+    tmax = np.full(n, 1e34, np.float32)
+    r_obj, r_t = ref.find_nearest(O, D, tmax, qbvh=True)
+    o_obj, o_t = orc.find_nearest(O, D, tmax)
+    assert np.array_equal(o_obj, r_obj) and same(o_t, r_t)
+    b_obj, _ = ref.find_nearest(O, D, tmax, qbvh=False)
+    assert (b_obj != r_obj).sum() > 0  # the two traversals of the reference do disagree on some of these rays
+    ts = (np.minimum(r_t, 50) * rng.uniform(0.2, 1.5, n)).astype(np.float32)
+    assert np.array_equal(orc.is_occluded(O, D, ts), ref.is_occluded(O, D, ts, qbvh=True))
+    cam, seeds = api.default_camera(320, 180), api.seed_table(320 * 180)
+    assert same(orc.sample(320, 180, cam, seeds, 5, 2), ref.sample(seeds, 5, 2, qbvh=True))
+    assert same(orc.trace(320, 180, cam, api.RAYTRACING, 5), ref.trace(api.RAYTRACING, 5, qbvh=True))
