@@ -186,6 +186,7 @@ def host_lib():
         L.rth_scene_load_obj_mtl.argtypes = L.rth_scene_load_obj.argtypes
         L.rth_scene_load_texture_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
         L.rth_scene_finalize.argtypes = [C.c_void_p, C.c_int]
+        L.rth_scene_build_qbvh.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rth_scene_set_lights.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rth_scene_desc.argtypes = [C.c_void_p]
         L.rth_scene_desc.restype = C.POINTER(SceneDesc)
@@ -294,6 +295,14 @@ class HostScene:
     def finalize(self, builder=REFERENCE_SAH):
         self.L.rth_scene_finalize(self.h, builder)
         return self
+
+    def build_qbvh(self):
+        """BVH::BuildQBVH (bvh.h:213-249): the reference's 4-wide nodes as an (n, 32) uint32 array (6 x 4 floats of box planes, child[4], count[4])"""
+        n = self.L.rth_scene_build_qbvh(self.h, None, 0)
+        out = np.zeros((n, 32), np.uint32)
+        if n:
+            self.L.rth_scene_build_qbvh(self.h, _ptr(out), n)
+        return out
 
     def set_lights(self, intensity, pos=None, color=None, roof_color=None):
         """Scene::SetLightIntensity / SetLightPos / SetLightColor / SetRoofLightColor (scene.h:536-551)"""

@@ -274,6 +274,92 @@ __device__ __forceinline__ bool traverse( const DScene& s, f3 O, f3 D, f3 rD, Ra
 	return false;
 }
 
+// ---- the reference's default traversal, for the rays on which it differs from the binary one (option qbvh) --------------------
+// IntersectQBVH / IntersectQBVHShadowRay (bvh.h:579-638, 690-758) over the reference's own QBVH nodes, statement for statement:
+// the four children of a node are box-tested at once with the ray's t as it was BEFORE the walk (ray_t is never refreshed,
+// bvh.h:590, 603) and with _mm_min_ps / _mm_max_ps, which return their SECOND operand when either is NaN (bvh.h:465-486); children
+// are visited in slot order, a node is left at its first child == -1; leaf primitives are judged with a plain `t < ray.t`, so the
+// first one visited keeps an equal distance; the primitive root's own box is never tested.  Only rays with an infinite reciprocal
+// direction component come here (0 * inf = NaN is where the two traversals of the reference part ways): a few in a
+// thousand camera rays, so one lane walks one ray with an explicit frame stack (one entry per level:
+// node << 8 | prevOccluded << 7 | box mask << 3 | next slot).  Returns true iff ANY and occluded.
+__device__ __forceinline__ float sse_min( float a, float b ) { return a < b ? a : b; }
+__device__ __forceinline__ float sse_max( float a, float b ) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t qbvh_boxes( const DScene& s, uint32_t node, f3 O, f3 rD, float ray_t )
+{
+	const float4* q = s.qnodes + 8 * (size_t)node;
+	const float4 nx = q[0], xx = q[1], ny = q[2], xy = q[3], nz = q[4], xz = q[5];
+	const float bnx[4] = { nx.x, nx.y, nx.z, nx.w }, bxx[4] = { xx.x, xx.y, xx.z, xx.w }, bny[4] = { ny.x, ny.y, ny.z, ny.w };
+	const float bxy[4] = { xy.x, xy.y, xy.z, xy.w }, bnz[4] = { nz.x, nz.y, nz.z, nz.w }, bxz[4] = { xz.x, xz.y, xz.z, xz.w };
+	uint32_t mask = 0;
+#pragma unroll
+	for (int l = 0; l < 4; l++)
+	{
+		const float tx1 = ( bnx[l] - O.x ) * rD.x, tx2 = ( bxx[l] - O.x ) * rD.x;
+		float tmin = sse_min( tx1, tx2 ), tmax = sse_max( tx1, tx2 );
+		const float ty1 = ( bny[l] - O.y ) * rD.y, ty2 = ( bxy[l] - O.y ) * rD.y;
+		tmin = sse_max( tmin, sse_min( ty1, ty2 ) ), tmax = sse_min( tmax, sse_max( ty1, ty2 ) );
+		const float tz1 = ( bnz[l] - O.z ) * rD.z, tz2 = ( bxz[l] - O.z ) * rD.z;
+		tmin = sse_max( tmin, sse_min( tz1, tz2 ) ), tmax = sse_min( tmax, sse_max( tz1, tz2 ) );
+		if (tmax >= tmin && tmin < ray_t && tmax > 0) mask |= 1u << l;
+	}
+	return mask;
+}
+template <bool ANY>
+__device__ __forceinline__ bool traverse_qbvh( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride )
+{
+	const float ray_t = h.t;
+	uint32_t node = s.qroot, slot = 0, mask = qbvh_boxes( s, node, O, rD, ray_t );
+	bool prev = false;   // ANY: prevOccluded of the current call (bvh.h:724)
+	bool anyHit = false; // ANY: ray.objIdx != -1
+	int sp = 0, best = -1;
+	for (;;)
+	{
+		bool leave = false, result = false; // leave the current call, with this return value (ANY)
+		if (slot < 4)
+		{
+			const int4 ch = *(const int4*)( s.qnodes + 8 * (size_t)node + 6 ), cn = *(const int4*)( s.qnodes + 8 * (size_t)node + 7 );
+			const int c = slot == 0 ? ch.x : slot == 1 ? ch.y : slot == 2 ? ch.z : ch.w, n = slot == 0 ? cn.x : slot == 1 ? cn.y : slot == 2 ? cn.z : cn.w;
+			if (c == -1) leave = true, result = false; // bvh.h:611 `return`, :727 `return false`
+			else if (!( mask >> slot & 1u )) slot++;
+			else if (n > 0)
+			{
+				for (int j = 0; j < n && !leave; j++)
+				{
+					h.pos = -1; // plain `t < ray.t` (primitive.h:68, 116, 122): no (t, position) rule here, the visiting order decides
+					if (isect_prim<ANY>( s, c + j, O, D, h )) best = c + j, anyHit = true;
+					if (ANY && anyHit) leave = true, result = true; // bvh.h:738, 744: `if (ray.objIdx != -1) return true`
+				}
+				slot++;
+			}
+			else if (ANY && prev) slot++; // `prevOccluded || ...`: the call is not made
+			else
+			{
+				stack[sp * stride] = node << 8 | ( prev ? 128u : 0u ) | mask << 3 | ( slot + 1 );
+				sp++;
+				node = (uint32_t)c, slot = 0, prev = false, mask = qbvh_boxes( s, node, O, rD, ray_t );
+			}
+		}
+		else leave = true, result = prev; // bvh.h:757
+		if (leave)
+		{
+			if (sp == 0) { h.pos = best; return ANY && result; }
+			const uint32_t e = stack[--sp * stride];
+			node = e >> 8, slot = e & 7u, mask = ( e >> 3 ) & 15u;
+			prev = ( e & 128u ) != 0 || ( ANY && result );
+		}
+	}
+}
+// a ray with an infinite reciprocal direction component: the reference's default traversal where the scene carries it (option
+// qbvh), else its binary traversal with the scalar slab test's NaN propagation
+template <bool ANY>
+__device__ __forceinline__ bool walk_inexact( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride )
+{
+	if (s.qnodes) return traverse_qbvh<ANY>( s, O, D, rD, h, stack, stride );
+	TravCount tc = {};
+	return traverse<ANY, true, false>( s, O, D, rD, h, stack, stride, tc );
+}
+
 // ---- the same traversal cut into steps, for the persistent kernels that refill idle lanes with new rays ----------
 template <bool EXACT>
 __device__ __forceinline__ uint32_t bvh_enter( const DScene& s, f3 O, f3 rD, float t )
@@ -735,7 +821,8 @@ __device__ __forceinline__ void find_nearest( const DScene& s, f3 O, f3 D, RayHi
 	isect_analytic( s, O, D, h );
 	if (s.n_bvh_prims == 0) return;
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (__any( inexact )) traverse<false, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
+	if (s.qnodes) { if (inexact) traverse_qbvh<false>( s, O, D, rD, h, stack, stride ); else traverse<false, false, COUNT>( s, O, D, rD, h, stack, stride, cnt ); }
+	else if (__any( inexact )) traverse<false, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 	else traverse<false, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 }
 // Scene::IsOccluded (scene.h:369-379): quad, cube with the shrinking ray.t, then planes and BVH with early out.
@@ -751,6 +838,7 @@ __device__ __forceinline__ bool is_occluded( const DScene& s, f3 O, f3 D, float 
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	if (s.qnodes) return inexact ? traverse_qbvh<true>( s, O, D, rD, h, stack, stride ) : traverse<true, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 	if (__any( inexact )) return traverse<true, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 	return traverse<true, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 }

@@ -93,6 +93,7 @@ __device__ __forceinline__ bool begin_closest( const DScene& s, f3 O, f3 D, RayH
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
+	if (inexact && s.qnodes) return true; // IntersectQBVH never tests the primitive root's own box (bvh.h:603)
 	return ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
 }
 // Same for Scene::IsOccluded (scene.h:369-379): quad and cube with the shrinking ray.t, then the planes with early out.
@@ -106,7 +107,7 @@ __device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tm
 	if (occluded || s.n_bvh_prims == 0) return;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	walk = ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
+	walk = ( inexact && s.qnodes ) || ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
 }
 
 // ---- ray generation (bounce 0): camera ray, per-(pixel, sample) rng state, analytic part of FindNearest --------------
@@ -320,6 +321,14 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 						inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 						if (use_wide && !inexact && !resumed) cur = s.wide_root;
+						if (inexact && s.qnodes)
+						{
+							// option qbvh: this ray is one of the few on which the reference's two traversals differ; it walks the
+							// reference's QBVH here and now, whole (never parked), and retires with the next round
+							if (ANY) occluded = traverse_qbvh<true>( s, O, D, rD, h, stack, BLOCK );
+							else traverse_qbvh<false>( s, O, D, rD, h, stack, BLOCK );
+							cur = RT_DONE, inexact = false;
+						}
 					}
 					chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
 					if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
@@ -710,7 +719,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 					nExtWalk++;
 					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-					if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, per_wave, tc );
+					if (inexact) walk_inexact<false>( s, O, D, rD, h, stack, per_wave );
 					else if (s.wide) traverse_wide<false>( s, O, D, rD, h, stack, per_wave );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
 				}
@@ -730,7 +739,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc )
+						const bool occ = inexact ? walk_inexact<true>( s, v.shO, v.shD, rD, sh, stack, per_wave )
 							: s.wide ? traverse_wide<true>( s, v.shO, v.shD, rD, sh, stack, per_wave ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc );
 						if (!occ) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
@@ -829,7 +838,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 					// rays that the 4-wide nodes cannot take walk the pairs, the four lanes in step (same values to the same column)
-					if (inexact) traverse<false, true, false>( s, O, D, rD, h, stack, stride, tc );
+					if (inexact) walk_inexact<false>( s, O, D, rD, h, stack, stride );
 					else if (s.wide) team_traverse_wide<false>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, stride, tc );
 				}
@@ -849,7 +858,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						const bool occ = inexact ? traverse<true, true, false>( s, v.shO, v.shD, rD, sh, stack, stride, tc )
+						const bool occ = inexact ? walk_inexact<true>( s, v.shO, v.shD, rD, sh, stack, stride )
 							: s.wide ? team_traverse_wide<true>( s, j, v.shO, v.shD, rD, sh, stack, stride, nStepsAny, nPrimsAny )
 							: traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, stride, tc );
 						if (!occ && j == 0) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
@@ -892,12 +901,12 @@ __device__ __forceinline__ void wave_find_nearest( const DScene& s, int lane, f3
 	if (s.n_bvh_prims == 0) return;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) == RT_DONE) return;
+	if (!( inexact && s.qnodes ) && ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) == RT_DONE) return;
 	walked = true;
 	TravCount tc = {};
 	// rays the 4-wide nodes cannot take, and rays whose frontier outgrows the LDS, walk as in k_tail: the 64 lanes in step,
 	// one stack column (the same values to the same addresses)
-	if (inexact) { traverse<false, true, false>( s, O, D, rD, h, L.nref, 1, tc ); return; }
+	if (inexact) { walk_inexact<false>( s, O, D, rD, h, L.nref, 1 ); return; }
 	if (!s.wide) { traverse<false, false, false>( s, O, D, rD, h, L.nref, 1, tc ); return; }
 	bool overflow;
 	wave_traverse_wide<false>( s, lane, O, D, rD, h, L, overflow, nIter );
@@ -910,11 +919,11 @@ __device__ __forceinline__ bool wave_is_occluded( const DScene& s, int lane, f3 
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (( inexact ? bvh_enter<true>( s, O, rD, tmaxRay ) : bvh_enter<false>( s, O, rD, tmaxRay ) ) == RT_DONE) return false;
+	if (!( inexact && s.qnodes ) && ( inexact ? bvh_enter<true>( s, O, rD, tmaxRay ) : bvh_enter<false>( s, O, rD, tmaxRay ) ) == RT_DONE) return false;
 	walked = true;
 	RayHit sh; sh.t = tmaxRay, sh.obj = -1, sh.pos = -1;
 	TravCount tc = {};
-	if (inexact) return traverse<true, true, false>( s, O, D, rD, sh, L.nref, 1, tc );
+	if (inexact) return walk_inexact<true>( s, O, D, rD, sh, L.nref, 1 );
 	if (!s.wide) return traverse<true, false, false>( s, O, D, rD, sh, L.nref, 1, tc );
 	bool overflow;
 	const bool occ = wave_traverse_wide<true>( s, lane, O, D, rD, sh, L, overflow, nIter );

@@ -53,6 +53,11 @@ struct DScene
 	// scene.h:70-75); pair_d[k] = d of plane k.  See isect_planes.
 	int plane_pairs;
 	float pair_d[6];
+	// option qbvh: the reference's own 4-wide QBVH (SIMD_BVH_Node, bvh.h:18-27: 8 x float4 per node -- bminx4, bmaxx4, bminy4,
+	// bmaxy4, bminz4, bmaxz4, child[4], count[4]; leaf children hold device positions) for the rays whose reciprocal direction has
+	// an infinite component (rt_device.h: traverse_qbvh); null: off.  qroot = the node IntersectQBVH starts at (bvh.h:603).
+	const float4* __restrict__ qnodes;
+	uint32_t qroot;
 };
 
 #define BLOCK 256   // traversal and per-pixel kernels

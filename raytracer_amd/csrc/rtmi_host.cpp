@@ -6,6 +6,7 @@
 // rt_kernels.hip (see raytracer_amd/build.py)
 #include "rt_shared.h"
 #include "../../include/rtmi.h"
+#include "../host/qbvh.h"
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -94,6 +95,7 @@ struct rtmi_ctx
 	hipStream_t side = 0;        // a bounce's shadow walk runs here, beside the next bounce's closest-hit walk on the main stream (RTMI_OVERLAP=0: on the main stream)
 	bool overlap_on = true;
 	bool plane_pairs_on = true;  // option plane_pairs = 0: the generic plane loop even for the reference's room (isect_planes); takes effect at the next upload
+	bool qbvh_on = false;        // option qbvh = 1: results follow the reference's default traversal, IntersectQBVH (rtmi_upload_scene); takes effect at the next upload
 	bool wide_on = true;         // RTMI_WIDE=0: k_trace walks the pairs instead of the 4-wide nodes with quantised boxes (rt_device.h: wide_step)
 	int refill = 16;        // refill a wave of k_trace when at least this many lanes are idle (8 / 24 / 32: within 1 %)
 	int max_blocks = 1024;  // resident 256-thread blocks for the persistent kernels (set from LDS use at upload)
@@ -480,7 +482,7 @@ static void set_max_blocks( rtmi_ctx* c )
 static int set_lanes( rtmi_ctx* c );
 struct OptDesc { const char* key; long long lo, hi; };
 static const OptDesc g_opts[] = {
-	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "plane_pairs", 0, 1 }, { "carry", 0, 1 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
+	{ "log_bounces", 0, 1 }, { "overlap", 0, 1 }, { "wide", 0, 1 }, { "plane_pairs", 0, 1 }, { "qbvh", 0, 1 }, { "carry", 0, 1 }, { "slots", 1, MAX_SLOTS }, { "tail_paths", 0, 1ll << 32 },
 	{ "carry_cap", 1, 1ll << 24 }, { "left_cap", 1, 1ll << 20 }, { "batch", 0, 1 << 20 }, { "check_launches", 0, 1 }, { "hook_kernel", 0, 2 }, { "tail_team", 0, 1 },
 	{ "tail_wave", 0, 1 }, { "wave_below", 0, 1 << 18 }, { "carry_min", 0, 1 << RTMI_SLOT_BITS }, { "lanes", 1, 2 }, { "last_round_bounces", 0, 1 << 30 }, { "preview_reads", 0, 1 },
 };
@@ -496,6 +498,7 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 	else if (is( "overlap" )) c->overlap_on = v != 0 && c->side != 0;
 	else if (is( "wide" )) c->wide_on = v != 0;
 	else if (is( "plane_pairs" )) c->plane_pairs_on = v != 0;
+	else if (is( "qbvh" )) c->qbvh_on = v != 0;
 	else if (is( "carry" )) { c->carry_on = v != 0; if (!c->tail_paths_set) c->tail_paths = c->carry_on ? 1u << 22 : c->small_paths; }
 	else if (is( "tail_paths" )) c->tail_paths = (uint32_t)std::min<long long>( v, 0xFFFFFFFFll ), c->tail_paths_set = true;
 	else if (is( "batch" )) c->batch_opt = (int)v;
@@ -543,6 +546,7 @@ static long long read_option( rtmi_ctx* c, const char* key, bool& found )
 	if (is( "overlap" )) return c->overlap_on;
 	if (is( "wide" )) return c->wide_on;
 	if (is( "plane_pairs" )) return c->plane_pairs_on;
+	if (is( "qbvh" )) return c->qbvh_on;
 	if (is( "carry" )) return c->carry_on;
 	if (is( "slots" )) return c->n_slots;
 	if (is( "tail_paths" )) return c->tail_paths;
@@ -570,7 +574,7 @@ static int sync_child( rtmi_ctx* c )
 	rtmi_ctx* k = c->child;
 	if (!k) return RTMI_OK;
 	k->ds = c->ds, k->has_scene = c->has_scene, k->stack_depth = c->stack_depth, k->walk_depth = c->walk_depth;
-	k->overlap_on = c->overlap_on && k->side != 0, k->wide_on = c->wide_on, k->plane_pairs_on = c->plane_pairs_on, k->refill = c->refill, k->max_blocks = c->max_blocks;
+	k->overlap_on = c->overlap_on && k->side != 0, k->wide_on = c->wide_on, k->plane_pairs_on = c->plane_pairs_on, k->qbvh_on = c->qbvh_on, k->refill = c->refill, k->max_blocks = c->max_blocks;
 	for (int i = 0; i < 2; i++) k->grid_closest[i] = c->grid_closest[i], k->grid_any[i] = c->grid_any[i];
 	k->cam = c->cam, k->seeds = c->seeds, k->accum = c->accum, k->late = c->late, k->odd = c->odd;
 	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->count_lag = c->count_lag, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
@@ -908,13 +912,67 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	std::vector<void*> allocs;
 	auto bail = [&]( int code ) { for (void* p : allocs) (void)hipFree( p ); return code; };
 	int r;
-	int maxDepth = 0, wideNeed = 0;
+	int maxDepth = 0, wideNeed = 0, qdepthNeed = 0;
 	ds.n_quads = d->n_quads, ds.n_spheres = d->n_spheres, ds.n_cubes = d->n_cubes, ds.n_planes = d->n_planes, ds.n_tris = d->n_triangles, ds.n_bvh_prims = nbvh;
 	if (nbvh > 0)
 	{
 		const int nn = d->n_nodes;
 		if (( nn - 3 ) % 2 != 0) return fail( c, RTMI_ERR_BVH, "n_nodes must be 3 + 2*pairs" );
 		const int npairs = ( nn - 3 ) / 2;
+		// Option qbvh: the reference's DEFAULT traversal (Scene::useQBVH = true, scene.h:585) differs from its binary one in two
+		// things a result can depend on: the order in which leaves are visited (the first of equally distant primitives wins,
+		// primitive.h:68) and, for rays with an infinite reciprocal direction component, which boxes are tested and how the SSE
+		// min / max treat the NaN of 0 * inf (bvh.h:465-486).  So with the option on the library rebuilds the
+		// reference's QBVH from the node array (BuildQBVH / CollapseBVH, bvh.h:75-249), (1) lays the leaf-ordered primitive
+		// records out in the QBVH's visiting order, so that the (t, position) rule of every walker breaks ties as IntersectQBVH
+		// does, and (2) uploads the QBVH nodes: rays with an infinite reciprocal component walk them with the SSE semantics
+		// (rt_device.h: traverse_qbvh), all others walk the 4-wide / pair nodes as always (same boxes bar the order of tests).
+		std::vector<int> newpos; // reference position k (primitiveIdx[k]) -> device position; identity without the option
+		std::vector<rtmi::QbvhNode> qn;
+		int qdepth = 0;
+		if (c->qbvh_on)
+		{
+			// BuildQbvh recurses over the node array: only over one that is a tree (checked in full further down, with messages)
+			std::vector<uint8_t> seen( (size_t)nn, 0 );
+			std::vector<int> stk = { 2 };
+			bool tree = true;
+			size_t covered = 0;
+			while (!stk.empty() && tree)
+			{
+				const int i = stk.back();
+				stk.pop_back();
+				if (i < 2 || i >= nn || seen[i]) { tree = false; break; }
+				seen[i] = 1;
+				const rtmi_bvh_node& n = d->nodes[i];
+				if (n.primitiveCount > 0) { if (n.leftFirst < 0 || (long long)n.leftFirst + n.primitiveCount > nbvh) tree = false; else covered += (size_t)n.primitiveCount; }
+				else if (n.primitiveCount < 0 || n.leftFirst < 3 || n.leftFirst + 1 >= nn) tree = false;
+				else stk.push_back( n.leftFirst ), stk.push_back( n.leftFirst + 1 );
+			}
+			if (tree && covered == (size_t)nbvh && rtmi::BuildQbvh( d->nodes, nn, qn ))
+			{
+				// visiting order of IntersectQBVH (bvh.h:607-638): children in slot order, depth first
+				newpos.assign( (size_t)nbvh, -1 );
+				int next = 0;
+				std::function<void( int, int )> visit = [&]( int node, int depth ) {
+					qdepth = std::max( qdepth, depth );
+					for (int sl = 0; sl < 4; sl++)
+					{
+						rtmi::QbvhNode& q = qn[node];
+						if (q.child[sl] == -1) return;
+						if (q.count[sl] > 0)
+						{
+							const int first = q.child[sl];
+							for (int j = 0; j < q.count[sl]; j++) newpos[(size_t)first + j] = next + j;
+							q.child[sl] = next, next += q.count[sl];
+						}
+						else visit( q.child[sl], depth + 1 );
+					} };
+				visit( qn[0].child[1], 1 );
+				if (next != nbvh) { qn.clear(), newpos.clear(), qdepth = 0; } // (cannot happen for a tree that covers every position once)
+			}
+			else qn.clear();
+		}
+		auto device_pos = [&]( int k ) { return newpos.empty() ? k : newpos[(size_t)k]; };
 		std::vector<float4> pairs( (size_t)( npairs > 0 ? npairs : 1 ) * 4, make_float4( 0, 0, 0, 0 ) );
 		// A leaf reference holds count - 1 in 6 bits.  The reference's builder stops splitting whenever no split lowers the SAH
 		// cost (bvh.h:344), so coincident or degenerate geometry gives leaves of any size, which its traversal walks like any
@@ -937,7 +995,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 			if (n.primitiveCount > 0)
 			{
 				if (n.leftFirst < 0 || (long long)n.leftFirst + n.primitiveCount > nbvh) return false;
-				ref = chunked( n.leftFirst, n.primitiveCount, n );
+				ref = chunked( device_pos( n.leftFirst ), n.primitiveCount, n ); // (a leaf's primitives stay together and in order)
 				return true;
 			}
 			if (n.primitiveCount < 0 || n.leftFirst < 3 || n.leftFirst + 1 >= nn || ( ( n.leftFirst - 3 ) & 1 )) return false;
@@ -1003,7 +1061,17 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 				b = make_float4( v[4] - v[0], v[5] - v[1], v[6] - v[2], __builtin_bit_cast( float, triBase + ti ) );
 				cc = make_float4( v[8] - v[0], v[9] - v[1], v[10] - v[2], 0 );
 			}
-			prims[3 * (size_t)k] = a, prims[3 * (size_t)k + 1] = b, prims[3 * (size_t)k + 2] = cc;
+			const size_t at = (size_t)device_pos( k );
+			prims[3 * at] = a, prims[3 * at + 1] = b, prims[3 * at + 2] = cc;
+		}
+		if (!qn.empty())
+		{
+			float4* dqn = 0;
+			static_assert( sizeof( rtmi::QbvhNode ) == 128, "SIMD_BVH_Node layout (bvh.h:18-27)" );
+			if (( r = dev_upload( c, &dqn, (const float4*)qn.data(), qn.size() * 8, &allocs ) )) return bail( r );
+			ds.qnodes = dqn, ds.qroot = (uint32_t)qn[0].child[1];
+			if (c->log_bounces) fprintf( stderr, "rtmi: the reference's QBVH: %zu nodes, depth %d\n", qn.size(), qdepth );
+			qdepthNeed = qdepth + 2;
 		}
 		float4* dp = 0, *dq = 0;
 		if (( r = dev_upload( c, &dp, pairs.data(), pairs.size(), &allocs ) ) || ( r = dev_upload( c, &dq, prims.data(), prims.size(), &allocs ) )) return bail( r );
@@ -1102,6 +1170,7 @@ int rtmi_upload_scene( rtmi_ctx* c, const rtmi_scene_desc* d )
 	c->scene_allocs = allocs, c->ds = ds, c->has_scene = true;
 	c->stack_depth = std::max( 4, maxDepth + 1 );
 	c->walk_depth = std::max( c->stack_depth, wideNeed + 1 );
+	c->stack_depth = std::max( c->stack_depth, qdepthNeed ), c->walk_depth = std::max( c->walk_depth, qdepthNeed ); // (traverse_qbvh: one stack entry per level)
 	set_max_blocks( c );
 	return RTMI_OK;
 }

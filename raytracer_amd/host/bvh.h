@@ -15,6 +15,7 @@
 // Traversal lives on the device (HIP kernels behind include/rtmi.h), not here.
 #pragma once
 #include "rt_types.h"
+#include "qbvh.h"
 #include <vector>
 
 namespace rtmi {
@@ -47,6 +48,11 @@ public:
 	GPUBVHNode* gpuBvhNode = 0;
 	uint rootNodeIdx = 0, planeRootNodeIdx = 1, primitveRootNodeIdx = 2, nodesUsed = 3;
 	int maxDepth = 0; // depth of the deepest leaf below node 2 (the device traversal stack bound)
+	// QBVH (bvh.h:58-60): the reference's 4-wide collapse of the binary tree, its default traversal structure.  Built on demand
+	// by BuildQBVH(); the device builds its own copy from the node array when a handle's option qbvh is on (rtmi_upload_scene).
+	std::vector<QbvhNode> qbvhNode;
+	uint nodesUsedQBVH = 0;
+	bool BuildQBVH() { const bool ok = BuildQbvh( (const rtmi_bvh_node*)gpuBvhNode, (int)nodesUsed, qbvhNode ); nodesUsedQBVH = (uint)qbvhNode.size(); return ok; } // bvh.h:213-249
 
 	BVH() = default;
 	BVH( Sphere* spheres, int spheres_size, Plane* planes, int planes_size, Triangle* triangles, int triangles_size, Builder builder = REFERENCE_SAH );

@@ -61,6 +61,16 @@ void rth_scene_set_lights( void* s, float intensity, const float* pos3, const fl
 	if (color3) sc->SetLightColor( float3( color3[0], color3[1], color3[2] ) );
 	if (roof3) sc->SetRoofLightColor( float3( roof3[0], roof3[1], roof3[2] ) );
 }
+// BVH::BuildQBVH on the scene's tree (bvh.h:213-249): the number of QBVH nodes (0: the primitive root is a leaf), and, if `out` is
+// given, the nodes as 32 words each (SIMD_BVH_Node, bvh.h:18-27)
+int rth_scene_build_qbvh( void* s, void* out, int capacity )
+{
+	Scene* sc = (Scene*)s;
+	if (!sc->bvh || !sc->bvh->BuildQBVH()) return 0;
+	const int n = (int)sc->bvh->nodesUsedQBVH;
+	if (out && capacity >= n) memcpy( out, sc->bvh->qbvhNode.data(), (size_t)n * sizeof( QbvhNode ) );
+	return n;
+}
 void rth_scene_finalize( void* s, int builder ) { ( (Scene*)s )->Finalize( (BVH::Builder)builder ); }
 const rtmi_scene_desc* rth_scene_desc( void* s ) { return ( (Scene*)s )->Desc(); }
 void rth_scene_info( void* s, int* out )

@@ -238,3 +238,25 @@ def test_obj_ingest_at_scale(tmp_path):
     one = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, check=True).stdout.strip()
     import hashlib
     assert one == hashlib.sha1(np.ascontiguousarray(s.desc.arrays()["tri_verts"]).tobytes()).hexdigest()
+
+
+def test_host_build_qbvh_matches_the_reference_counts(default_scene):
+    """BVH::BuildQBVH of the host mirror (bvh.h:213-249 via host/qbvh.h): 812 nodes for the default scene (measured on the compiled
+    reference), as many as the oracle's independent restatement; every leaf position owned by exactly one slot."""
+    from oracle.oracle import Oracle
+    q = default_scene.build_qbvh()
+    o = Oracle(default_scene.desc)
+    assert o.set_qbvh(True)
+    assert len(q) == 812 == o.qbvh_nodes()
+    child, count = q[:, 24:28].view(np.int32), q[:, 28:32].view(np.int32)
+    nb = default_scene.info()["spheres"] + default_scene.info()["triangles"]
+    owned = np.zeros(nb, np.int32)
+    for n in range(1, len(q)):  # (node 0 holds the plane leaf and the primitive root)
+        for s in range(4):
+            if child[n, s] == -1:
+                assert (child[n, s:] == -1).all()  # the traversal leaves a node at its first empty slot (bvh.h:611)
+                break
+            if count[n, s] > 0:
+                owned[child[n, s]:child[n, s] + count[n, s]] += 1
+    assert (owned == 1).all()
+    assert child[0, 1] == 1 and count[0, 0] == default_scene.info()["planes"]

@@ -255,3 +255,82 @@ def test_plane_pairs_equal_the_plane_loop(default_scene, hook_kernel):
         res.append((obj, t, occ))
         d.close()
     assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(res[0], res[1]))
+
+
+def qbvh_oracle(desc):
+    o = Oracle(desc)
+    assert o.set_qbvh(True)
+    return o
+
+
+@pytest.mark.parametrize("hook_kernel", [0, 1, 2])
+def test_reference_default_traversal_option(default_scene, gold_720, gold_bvh, hook_kernel):
+    """Option qbvh: results follow the reference's DEFAULT traversal (Scene::useQBVH = true, scene.h:585; IntersectQBVH /
+    IntersectQBVHShadowRay, bvh.h:579-758) instead of its binary one.  With the option on, the primary hit map at 1280x720 equals
+    the reference-default map on ALL 921 600 rays (the 207 rays of column 640 included, golden qbvh_diff_*); the reference-held
+    cow / ball / mix vectors equal their *_qbvh results; fresh rays with zero direction components on box planes equal the
+    oracle's QBVH restatement (itself bit-exact against the compiled reference: tests/test_oracle_vs_ref.py); a path-traced image
+    matches the oracle's QBVH image.  Through every walker of the library (hook kernels 0, 1, 2)."""
+    W, H = 1280, 720
+    d = api.Device(W, H, qbvh=1, hook_kernel=hook_kernel)
+    d.upload(default_scene.desc)
+    d.set_camera(gold_720["camera"])
+    if hook_kernel == 0:
+        obj, t = d.trace_primary()
+        q_obj, q_t = gold_720["hit_obj_bvh"].astype(np.int32).copy(), gold_720["hit_t_bvh"].copy()
+        idx = gold_720["qbvh_diff_idx"]
+        q_obj[idx], q_t[idx] = gold_720["qbvh_diff_obj"], gold_720["qbvh_diff_t"]
+        assert np.array_equal(obj, q_obj) and np.array_equal(bits(t), bits(q_t))
+    orc = qbvh_oracle(default_scene.desc)
+    rng = np.random.default_rng(23)
+    n = 60000
+    O = np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1).astype(np.float32)
+    O[:6000] = np.round(O[:6000] * 4) / 4
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    D[:2000, 0] = 0
+    D[2000:4000, 1] = 0
+    D[4000:6000, 2] = 0
+    D[6000:6500, :2] = 0
+    tmax = np.full(n, 1e34, np.float32)
+    c_obj, c_t = orc.find_nearest(O, D, tmax)
+    g_obj, g_t = d.trace_rays(O, D, tmax)
+    assert np.array_equal(g_obj, c_obj) and np.array_equal(bits(g_t), bits(c_t))
+    b_obj, _ = Oracle(default_scene.desc).find_nearest(O, D, tmax)
+    assert (b_obj != c_obj).sum() > 0  # rays on which the reference's two traversals differ are in the set
+    ts = (np.minimum(c_t, 50) * rng.uniform(0.2, 1.5, n)).astype(np.float32)
+    assert np.array_equal(d.trace_rays(O, D, ts, any_hit=True)[0], orc.is_occluded(O, D, ts))
+    d.close()
+    # the reference-held tie vectors (coincident triangles, zero components): QBVH visiting order decides ties
+    for name in ("cow", "ball", "mix"):
+        s = build_fixture_scene(gold_bvh, name)
+        d = api.Device(64, 64, qbvh=1, hook_kernel=hook_kernel)
+        d.upload(s.desc)
+        Of, Df = gold_bvh[name + "_O"], gold_bvh[name + "_D"]
+        obj, t = d.trace_rays(Of, Df, np.full(len(Of), 1e34, np.float32))
+        assert np.array_equal(obj, gold_bvh[name + "_idx_qbvh"]) and np.array_equal(bits(t), bits(gold_bvh[name + "_t_qbvh"])), name
+        if name + "_occ_qbvh" in gold_bvh.files:
+            assert np.array_equal(d.trace_rays(Of, Df, gold_bvh[name + "_tshadow"], any_hit=True)[0], gold_bvh[name + "_occ_qbvh"]), name
+        d.close()
+
+
+def test_reference_default_traversal_images(default_scene):
+    """option qbvh through the renderer: path-traced and Whitted images at 320x180 against the oracle walking the reference's QBVH
+    (the centre column's rays have D.x = 0: SURVEY A.6), and the leaf order it imposes leaves the default contract alone."""
+    W, H = 320, 180
+    cam, seeds = api.default_camera(W, H), api.seed_table(W * H)
+    orc = qbvh_oracle(default_scene.desc)
+    d = api.Device(W, H, qbvh=1)
+    d.upload(default_scene.desc)
+    d.set_seeds(seeds)
+    d.set_camera(cam)
+    d.render(api.PATHTRACING, 0, 4, 1)
+    ref = orc.sample(W, H, cam, seeds, 0, 4)
+    assert float(np.sqrt(np.mean((d.accumulator()[..., :3].astype(np.float64) - ref[..., :3]) ** 2))) <= 4e-5
+    d.render(api.RAYTRACING, 0, 1, 1, 5, 0)
+    wref = orc.trace(W, H, cam, api.RAYTRACING, 5)
+    assert float(np.sqrt(np.mean((d.accumulator()[..., :3].astype(np.float64) - wref[..., :3]) ** 2))) <= 1e-5
+    obj, t = d.trace_primary()
+    o_obj, o_t = orc.primary_hits(W, H, cam)
+    assert np.array_equal(obj, o_obj) and np.array_equal(bits(t), bits(o_t))
+    d.close()
