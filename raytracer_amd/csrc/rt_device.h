@@ -66,23 +66,30 @@ struct RayHit { float t; int obj; int pos; };
 
 // ---- primitive intersection (closest-hit forms) ---------------------------------------------------------------
 // Quad::Intersect, primitive.h:284-295
-__device__ __forceinline__ void isect_quad( const DScene& s, int i, f3 O, f3 D, RayHit& h ) // (i == 0: every caller)
+__device__ __forceinline__ void isect_quad_rows( const m34& M, float size, int obj, f3 O, f3 D, RayHit& h )
 {
-	m34 M; M.r0 = s.quad0[0], M.r1 = s.quad0[1], M.r2 = s.quad0[2];
-	const float size = s.quad0[3].x;
 	const f3 o = xform_pos( O, M ), d = xform_vec( D, M );
 	const float t = o.y / -d.y;
 	if (t < h.t && t > 0)
 	{
 		const f3 I = o + t * d;
-		if (I.x > -size && I.x < size && I.z > -size && I.z < size) h.t = t, h.obj = i, h.pos = -1;
+		if (I.x > -size && I.x < size && I.z > -size && I.z < size) h.t = t, h.obj = obj, h.pos = -1;
 	}
 }
+__device__ __forceinline__ void isect_quad( const DScene& s, int i, f3 O, f3 D, RayHit& h ) // (i == 0: every caller)
+{
+	m34 M; M.r0 = s.quad0[0], M.r1 = s.quad0[1], M.r2 = s.quad0[2];
+	isect_quad_rows( M, s.quad0[3].x, i, O, D, h );
+}
 // Cube::Intersect, primitive.h:210-236
+__device__ __forceinline__ void isect_cube_rows( const m34& M, float4 b0, float4 b1, int obj, f3 O, f3 D, RayHit& h );
 __device__ __forceinline__ void isect_cube( const DScene& s, int i, f3 O, f3 D, RayHit& h )
 {
 	m34 M; M.r0 = s.cubes[8 * i], M.r1 = s.cubes[8 * i + 1], M.r2 = s.cubes[8 * i + 2];
-	const float4 b0 = s.cubes[8 * i + 3], b1 = s.cubes[8 * i + 4];
+	isect_cube_rows( M, s.cubes[8 * i + 3], s.cubes[8 * i + 4], s.n_quads + s.n_spheres + i, O, D, h );
+}
+__device__ __forceinline__ void isect_cube_rows( const m34& M, float4 b0, float4 b1, int obj, f3 O, f3 D, RayHit& h )
+{
 	const f3 o = xform_pos( O, M ), d = xform_vec( D, M );
 	const float rDx = 1 / d.x, rDy = 1 / d.y, rDz = 1 / d.z;
 	const bool sx = d.x < 0, sy = d.y < 0, sz = d.z < 0;
@@ -96,18 +103,17 @@ __device__ __forceinline__ void isect_cube( const DScene& s, int i, f3 O, f3 D, 
 	const float tzmax = ( ( sz ? b0.z : b1.z ) - o.z ) * rDz;
 	if (tmin > tzmax || tzmin > tmax) return;
 	tmin = smax( tmin, tzmin ), tmax = smin( tmax, tzmax );
-	const int obj = s.n_quads + s.n_spheres + i;
 	if (tmin > 0) { if (tmin < h.t) h.t = tmin, h.obj = obj, h.pos = -1; }
 	else if (tmax > 0) { if (tmax < h.t) h.t = tmax, h.obj = obj, h.pos = -1; }
 }
 // Plane::Intersect, primitive.h:154-158
-__device__ __forceinline__ void isect_plane( const DScene& s, int i, f3 O, f3 D, RayHit& h )
+__device__ __forceinline__ void isect_plane_nd( float4 p, int obj, f3 O, f3 D, RayHit& h )
 {
-	const float4 p = s.planes[i];
 	const f3 N = mk3( p );
 	const float t = -( dot3( O, N ) + p.w ) / ( dot3( D, N ) );
-	if (t < h.t && t > 0) h.t = t, h.obj = s.n_quads + s.n_spheres + s.n_cubes + i, h.pos = -1;
+	if (t < h.t && t > 0) h.t = t, h.obj = obj, h.pos = -1;
 }
+__device__ __forceinline__ void isect_plane( const DScene& s, int i, f3 O, f3 D, RayHit& h ) { isect_plane_nd( s.planes[i], s.n_quads + s.n_spheres + s.n_cubes + i, O, D, h ); }
 // Two opposite axis planes at once: plane k = (+e, d1), plane k + 1 = (-e, d2); o, dd = the ray's origin and direction
 // component on that axis.  With N = +-e the reference's dot products are the component itself (x * 1 + y * 0 + z * 0, exact for
 // finite rays up to the sign of a zero, which no outcome depends on: a zero numerator gives t = +-0, a zero denominator
@@ -159,13 +165,22 @@ __device__ __forceinline__ void isect_analytic( const DScene& s, f3 O, f3 D, Ray
 // in increasing primitiveIdx position and keeps the first of equal distances (strict `<`, primitive.h:68,116,122),
 // so "smallest (t, position)" is what it returns whatever the visiting order.
 template <bool ANY>
+__device__ __forceinline__ bool isect_record( float4 a, float4 b, float4 c, int pos, f3 O, f3 D, RayHit& h );
+template <bool ANY>
 __device__ __forceinline__ bool isect_prim( const DScene& s, int pos, f3 O, f3 D, RayHit& h )
 {
 	const float4 a = s.prims[3 * pos], b = s.prims[3 * pos + 1];
+	// (a sphere's record has no third quarter worth fetching)
+	const float4 c = __float_as_int( a.w ) == 0 ? s.prims[3 * pos + 2] : make_float4( 0, 0, 0, 0 );
+	return isect_record<ANY>( a, b, c, pos, O, D, h );
+}
+// one 48-byte primitive record {p1, tag 0} {e1, objIdx} {e2, -} (triangle) or {pos, tag 1} {r2, -, -, objIdx} (sphere) against the ray
+template <bool ANY>
+__device__ __forceinline__ bool isect_record( float4 a, float4 b, float4 c, int pos, f3 O, f3 D, RayHit& h )
+{
 	if (__float_as_int( a.w ) == 0)
 	{
 		// Triangle::Intersect, primitive.h:50-72 (edges precomputed on upload with the same two subtractions)
-		const float4 c = s.prims[3 * pos + 2];
 		const f3 p1 = mk3( a ), edge1 = mk3( b ), edge2 = mk3( c );
 		const f3 hh = cross3( D, edge2 );
 		const float det = dot3( edge1, hh );
@@ -351,11 +366,13 @@ __device__ __forceinline__ bool traverse_qbvh( const DScene& s, f3 O, f3 D, f3 r
 	}
 }
 // a ray with an infinite reciprocal direction component: the reference's default traversal where the scene carries it (option
-// qbvh), else its binary traversal with the scalar slab test's NaN propagation
-template <bool ANY>
+// qbvh), else its binary traversal with the scalar slab test's NaN propagation.  QBVH is a template parameter of every kernel
+// that walks rays: the instantiations a handle without the option launches carry none of traverse_qbvh's code or registers
+// (inlined into k_trace it cost 12 VGPRs and 4 % of the bench).
+template <bool ANY, bool QBVH>
 __device__ __forceinline__ bool walk_inexact( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride )
 {
-	if (s.qnodes) return traverse_qbvh<ANY>( s, O, D, rD, h, stack, stride );
+	if (QBVH) return traverse_qbvh<ANY>( s, O, D, rD, h, stack, stride );
 	TravCount tc = {};
 	return traverse<ANY, true, false>( s, O, D, rD, h, stack, stride, tc );
 }
@@ -814,19 +831,19 @@ __device__ __forceinline__ bool wave_traverse_wide( const DScene& s, int lane, f
 }
 
 // Scene::FindNearest (scene.h:359-368): quads[0], cubes[0], planes, BVH.  h.t carries the ray's tmax in.
-template <bool COUNT>
+template <bool COUNT, bool QBVH>
 __device__ __forceinline__ void find_nearest( const DScene& s, f3 O, f3 D, RayHit& h, uint32_t* stack, int stride, TravCount& cnt )
 {
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z ); // Ray ctor, primitive.h:11
 	isect_analytic( s, O, D, h );
 	if (s.n_bvh_prims == 0) return;
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (s.qnodes) { if (inexact) traverse_qbvh<false>( s, O, D, rD, h, stack, stride ); else traverse<false, false, COUNT>( s, O, D, rD, h, stack, stride, cnt ); }
+	if (QBVH) { if (inexact) traverse_qbvh<false>( s, O, D, rD, h, stack, stride ); else traverse<false, false, COUNT>( s, O, D, rD, h, stack, stride, cnt ); }
 	else if (__any( inexact )) traverse<false, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 	else traverse<false, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 }
 // Scene::IsOccluded (scene.h:369-379): quad, cube with the shrinking ray.t, then planes and BVH with early out.
-template <bool COUNT>
+template <bool COUNT, bool QBVH>
 __device__ __forceinline__ bool is_occluded( const DScene& s, f3 O, f3 D, float tmaxRay, uint32_t* stack, int stride, TravCount& cnt )
 {
 	RayHit h; h.t = tmaxRay, h.obj = -1, h.pos = -1;
@@ -838,7 +855,7 @@ __device__ __forceinline__ bool is_occluded( const DScene& s, f3 O, f3 D, float 
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (s.qnodes) return inexact ? traverse_qbvh<true>( s, O, D, rD, h, stack, stride ) : traverse<true, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
+	if (QBVH) return inexact ? traverse_qbvh<true>( s, O, D, rD, h, stack, stride ) : traverse<true, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 	if (__any( inexact )) return traverse<true, true, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 	return traverse<true, false, COUNT>( s, O, D, rD, h, stack, stride, cnt );
 }

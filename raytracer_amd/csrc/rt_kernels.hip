@@ -230,7 +230,7 @@ __device__ __forceinline__ void add_walked( const Sinks& k, uint32_t slot, bool 
 // bounce's shadow queue; its contribution then arrives late and may meet the same path's next shadow ray in one launch,
 // which is why the contributions of walked shadow rays are summed order-independently (Es, below).
 
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool QBVH>
 __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 						inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 						if (use_wide && !inexact && !resumed) cur = s.wide_root;
-						if (inexact && s.qnodes)
+						if (QBVH && inexact)
 						{
 							// option qbvh: this ray is one of the few on which the reference's two traversals differ; it walks the
 							// reference's QBVH here and now, whole (never parked), and retires with the next round
@@ -654,6 +654,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 // round holds one long path, and a thousand almost-empty resident waves would starve the next batches' bulk kernels).
 // Same device functions and the same per-path order of operations as the wavefront kernels: results do not depend on
 // when the host switches over or on the round lengths. ------------------------------------------------------------------
+template <bool QBVH>
 __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late )
 {
@@ -719,7 +720,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 					nExtWalk++;
 					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-					if (inexact) walk_inexact<false>( s, O, D, rD, h, stack, per_wave );
+					if (inexact) walk_inexact<false, QBVH>( s, O, D, rD, h, stack, per_wave );
 					else if (s.wide) traverse_wide<false>( s, O, D, rD, h, stack, per_wave );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, per_wave, tc );
 				}
@@ -739,7 +740,7 @@ __global__ __launch_bounds__( 1024 ) void k_tail( DScene s, PathState in, PathSt
 						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						const bool occ = inexact ? walk_inexact<true>( s, v.shO, v.shD, rD, sh, stack, per_wave )
+						const bool occ = inexact ? walk_inexact<true, QBVH>( s, v.shO, v.shD, rD, sh, stack, per_wave )
 							: s.wide ? traverse_wide<true>( s, v.shO, v.shD, rD, sh, stack, per_wave ) : traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, per_wave, tc );
 						if (!occ) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 					}
@@ -790,6 +791,7 @@ __global__ void k_tail_decide( DevCounters* ctr, const uint32_t* __restrict__ n_
 // tests child j of every 4-wide node and primitive j of every leaf, the rest of the bounce (analytic tests, shading, the
 // random stream) is computed identically by the four lanes, and lane 0 alone writes.  Same visiting order, same
 // arithmetic, same results as k_tail, which stays in charge of every round that is not a draining round with few paths.
+template <bool QBVH>
 __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
@@ -838,7 +840,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 					const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 					const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 					// rays that the 4-wide nodes cannot take walk the pairs, the four lanes in step (same values to the same column)
-					if (inexact) walk_inexact<false>( s, O, D, rD, h, stack, stride );
+					if (inexact) walk_inexact<false, QBVH>( s, O, D, rD, h, stack, stride );
 					else if (s.wide) team_traverse_wide<false>( s, j, O, D, rD, h, stack, stride, nSteps, nPrims );
 					else traverse<false, false, false>( s, O, D, rD, h, stack, stride, tc );
 				}
@@ -858,7 +860,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 						RayHit sh; sh.t = v.shT, sh.obj = -1, sh.pos = -1;
 						const f3 rD = mk3( 1 / v.shD.x, 1 / v.shD.y, 1 / v.shD.z );
 						const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-						const bool occ = inexact ? walk_inexact<true>( s, v.shO, v.shD, rD, sh, stack, stride )
+						const bool occ = inexact ? walk_inexact<true, QBVH>( s, v.shO, v.shD, rD, sh, stack, stride )
 							: s.wide ? team_traverse_wide<true>( s, j, v.shO, v.shD, rD, sh, stack, stride, nStepsAny, nPrimsAny )
 							: traverse<true, false, false>( s, v.shO, v.shD, rD, sh, stack, stride, tc );
 						if (!occ && j == 0) add_walked( sinks, slot, late, make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
@@ -894,6 +896,7 @@ __global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, Pa
 // Below a few thousand live paths even a team leaves 60 lanes of its wave idle while its path's walk is a chain of ~30
 // dependent steps.  Here the whole wave walks the one path breadth-first (rt_device.h: wave_traverse_wide), the analytic
 // primitives are tested one per lane, and shading runs replicated as in k_tail_team; lane 0 writes.
+template <bool QBVH>
 __device__ __forceinline__ void wave_find_nearest( const DScene& s, int lane, f3 O, f3 D, float t0, RayHit& h, WaveLds& L, bool& walked, uint32_t& nIter )
 {
 	wave_analytic( s, lane, O, D, t0, h );
@@ -901,17 +904,18 @@ __device__ __forceinline__ void wave_find_nearest( const DScene& s, int lane, f3
 	if (s.n_bvh_prims == 0) return;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (!( inexact && s.qnodes ) && ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) == RT_DONE) return;
+	if (!( QBVH && inexact ) && ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) == RT_DONE) return;
 	walked = true;
 	TravCount tc = {};
 	// rays the 4-wide nodes cannot take, and rays whose frontier outgrows the LDS, walk as in k_tail: the 64 lanes in step,
 	// one stack column (the same values to the same addresses)
-	if (inexact) { walk_inexact<false>( s, O, D, rD, h, L.nref, 1 ); return; }
+	if (inexact) { walk_inexact<false, QBVH>( s, O, D, rD, h, L.nref, 1 ); return; }
 	if (!s.wide) { traverse<false, false, false>( s, O, D, rD, h, L.nref, 1, tc ); return; }
 	bool overflow;
 	wave_traverse_wide<false>( s, lane, O, D, rD, h, L, overflow, nIter );
 	if (overflow) traverse_wide<false>( s, O, D, rD, h, L.nref, 1 );
 }
+template <bool QBVH>
 __device__ __forceinline__ bool wave_is_occluded( const DScene& s, int lane, f3 O, f3 D, float tmaxRay, WaveLds& L, bool& walked, uint32_t& nIter )
 {
 	walked = false;
@@ -919,18 +923,19 @@ __device__ __forceinline__ bool wave_is_occluded( const DScene& s, int lane, f3 
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (!( inexact && s.qnodes ) && ( inexact ? bvh_enter<true>( s, O, rD, tmaxRay ) : bvh_enter<false>( s, O, rD, tmaxRay ) ) == RT_DONE) return false;
+	if (!( QBVH && inexact ) && ( inexact ? bvh_enter<true>( s, O, rD, tmaxRay ) : bvh_enter<false>( s, O, rD, tmaxRay ) ) == RT_DONE) return false;
 	walked = true;
 	RayHit sh; sh.t = tmaxRay, sh.obj = -1, sh.pos = -1;
 	TravCount tc = {};
-	if (inexact) return walk_inexact<true>( s, O, D, rD, sh, L.nref, 1 );
+	if (inexact) return walk_inexact<true, QBVH>( s, O, D, rD, sh, L.nref, 1 );
 	if (!s.wide) return traverse<true, false, false>( s, O, D, rD, sh, L.nref, 1, tc );
 	bool overflow;
 	const bool occ = wave_traverse_wide<true>( s, lane, O, D, rD, sh, L, overflow, nIter );
 	return overflow ? traverse_wide<true>( s, O, D, rD, sh, L.nref, 1 ) : occ;
 }
 
-__global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
+template <bool QBVH>
+__global__ __launch_bounds__( 64 * WAVE_WG, 4 ) void k_tail_wave( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
 	__shared__ WaveLds lds[WAVE_WG];
@@ -956,7 +961,7 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 		{
 			RayHit h;
 			bool walked;
-			wave_find_nearest( s, lane, O, D, 1e34f, h, L, walked, nIter );
+			wave_find_nearest<QBVH>( s, lane, O, D, 1e34f, h, L, walked, nIter );
 			nExt++, nExtWalk += walked ? 1 : 0;
 			Vertex v;
 			const bool late = age == META_AGE_LATE;
@@ -965,7 +970,7 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 			if (v.shadow_any)
 			{
 				nSh++;
-				const bool occ = wave_is_occluded( s, lane, v.shO, v.shD, v.shT, L, walked, nIterAny );
+				const bool occ = wave_is_occluded<QBVH>( s, lane, v.shO, v.shD, v.shT, L, walked, nIterAny );
 				nShWalk += walked ? 1 : 0;
 				if (!occ && lane == 0)
 				{
@@ -992,6 +997,7 @@ __global__ __launch_bounds__( 64 * WAVE_WG ) void k_tail_wave( DScene s, PathSta
 }
 
 // the parity hook through the same code (option hook_kernel = 2): wave w walks caller rays w, w + waves, ...
+template <bool QBVH>
 __global__ __launch_bounds__( 256 ) void k_rays_wave( DScene s, int n, const float* __restrict__ O3, const float* __restrict__ D3, const float* __restrict__ tmax,
 	int any_hit, int* __restrict__ obj_out, float* __restrict__ t_out )
 {
@@ -1006,13 +1012,13 @@ __global__ __launch_bounds__( 256 ) void k_rays_wave( DScene s, int n, const flo
 		bool walked;
 		if (any_hit)
 		{
-			const bool occ = wave_is_occluded( s, lane, O, D, tmax[i], L, walked, nIter );
+			const bool occ = wave_is_occluded<QBVH>( s, lane, O, D, tmax[i], L, walked, nIter );
 			if (lane == 0) obj_out[i] = occ ? 1 : 0, t_out[i] = tmax[i];
 		}
 		else
 		{
 			RayHit h;
-			wave_find_nearest( s, lane, O, D, tmax[i], h, L, walked, nIter );
+			wave_find_nearest<QBVH>( s, lane, O, D, tmax[i], h, L, walked, nIter );
 			if (lane == 0) obj_out[i] = h.obj, t_out[i] = h.t;
 		}
 	}
@@ -1214,6 +1220,7 @@ __global__ __launch_bounds__( BLOCK ) void k_vignette( uint32_t* __restrict__ px
 }
 
 // ---- parity hook: caller rays -----------------------------------------------------------------------------------
+template <bool QBVH>
 __global__ __launch_bounds__( BLOCK ) void k_trace_rays( DScene s, int n, const float* __restrict__ O3, const float* __restrict__ D3, const float* __restrict__ tmax,
 	int any_hit, int* __restrict__ obj_out, float* __restrict__ t_out )
 {
@@ -1227,13 +1234,13 @@ __global__ __launch_bounds__( BLOCK ) void k_trace_rays( DScene s, int n, const 
 	{
 		if (any_hit)
 		{
-			const bool occ = is_occluded<false>( s, O, D, tmax[k], lds_stack + threadIdx.x, BLOCK, tc );
+			const bool occ = is_occluded<false, QBVH>( s, O, D, tmax[k], lds_stack + threadIdx.x, BLOCK, tc );
 			obj_out[k] = occ ? 1 : 0, t_out[k] = tmax[k];
 		}
 		else
 		{
 			RayHit h; h.t = tmax[k], h.obj = -1, h.pos = -1;
-			find_nearest<false>( s, O, D, h, lds_stack + threadIdx.x, BLOCK, tc );
+			find_nearest<false, QBVH>( s, O, D, h, lds_stack + threadIdx.x, BLOCK, tc );
 			obj_out[k] = h.obj, t_out[k] = h.t;
 		}
 	}
@@ -1299,6 +1306,7 @@ __global__ __launch_bounds__( BLOCK ) void k_rays_any_result( const long long* _
 // Each pending call is a frame; a GLASS frame is visited up to three times (before the reflection child, before the
 // refraction child, after both).  Frames live in a per-thread slice of a global buffer (depth <= max_depth).
 
+template <bool QBVH>
 __device__ __forceinline__ f3 direct_illumination( const DScene& s, f3 I, f3 N, uint32_t* stack, int stride ) // scene.h:490-515
 {
 	f3 acc = mk3( 0, 0, 0 );
@@ -1311,7 +1319,7 @@ __device__ __forceinline__ f3 direct_illumination( const DScene& s, f3 I, f3 N, 
 		const f3 so = I + dirN * eps;
 		const float mag = magnitude3( dir );
 		const float st = mag - eps * 2;
-		if (!is_occluded<false>( s, so, dirN, st, stack, stride, tc ))
+		if (!is_occluded<false, QBVH>( s, so, dirN, st, stack, stride, tc ))
 		{
 			const float distanceEnergy = 1 / sqrf_( st );
 			const float d = dot3( N, dirN );
@@ -1322,6 +1330,7 @@ __device__ __forceinline__ f3 direct_illumination( const DScene& s, f3 I, f3 N, 
 	return acc;
 }
 
+template <bool QBVH>
 __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa,
 	WFrame* __restrict__ frames, float4* __restrict__ acc )
 {
@@ -1350,7 +1359,7 @@ __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int
 			{
 				if (depth >= max_depth) { ret = mk3( 0, 0, 0 ), depth--; continue; } // renderer.cpp:135-136
 				RayHit h; h.t = 1e34f, h.obj = -1, h.pos = -1;
-				find_nearest<false>( s, f.O, f.D, h, stack, BLOCK, tc );
+				find_nearest<false, QBVH>( s, f.O, f.D, h, stack, BLOCK, tc );
 				if (h.obj == -1) { ret = mk3( 0, 0, 0 ), depth--; continue; }
 				const f3 I = f.O + h.t * f.D;
 				HitAttr a;
@@ -1361,7 +1370,7 @@ __global__ __launch_bounds__( BLOCK ) void k_whitted( DScene s, CamProp cam, int
 				if (mode == RTMI_DISTANCE) { ret = 0.1f * mk3( h.t, h.t, h.t ), depth--; continue; }
 				if (type == RTMI_DIFFUSE || type == RTMI_LIGHT)
 				{
-					ret = a.albedo / 3.14159265358979323846264f * direct_illumination( s, I, a.N, stack, BLOCK );
+					ret = a.albedo / 3.14159265358979323846264f * direct_illumination<QBVH>( s, I, a.N, stack, BLOCK );
 					depth--;
 				}
 				else if (type == RTMI_MIRROR)
@@ -1457,36 +1466,44 @@ void rtk_primary( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene 
 {
 	hipLaunchKernelGGL( k_primary, grid, block, lds, stream, s, st, E, Es, N, cam, W, H, invW, invH, seeds, sample_begin, sample_stride, wq, ctr );
 }
-void rtk_trace( bool any, bool count, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr )
+void rtk_trace( bool any, bool count, bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr )
 {
-	if (any && count) hipLaunchKernelGGL( ( k_trace<true, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (any && !count) hipLaunchKernelGGL( ( k_trace<true, false> ), grid, block, lds, stream, s, a, ctr );
-	else if (!any && count) hipLaunchKernelGGL( ( k_trace<false, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (!any && !count) hipLaunchKernelGGL( ( k_trace<false, false> ), grid, block, lds, stream, s, a, ctr );
+	if (any && count && qbvh) hipLaunchKernelGGL( ( k_trace<true, true, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (any && count && !qbvh) hipLaunchKernelGGL( ( k_trace<true, true, false> ), grid, block, lds, stream, s, a, ctr );
+	else if (any && !count && qbvh) hipLaunchKernelGGL( ( k_trace<true, false, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (any && !count && !qbvh) hipLaunchKernelGGL( ( k_trace<true, false, false> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && count && qbvh) hipLaunchKernelGGL( ( k_trace<false, true, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && count && !qbvh) hipLaunchKernelGGL( ( k_trace<false, true, false> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && !count && qbvh) hipLaunchKernelGGL( ( k_trace<false, false, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && !count && !qbvh) hipLaunchKernelGGL( ( k_trace<false, false, false> ), grid, block, lds, stream, s, a, ctr );
 }
 void rtk_shade( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, uint32_t* wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {
 	hipLaunchKernelGGL( k_shade, grid, block, lds, stream, s, in, out, sq, sinks, n_in, n_out, wq_out, n_walk_out, n_shadow, ctr );
 }
-void rtk_tail( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late )
+void rtk_tail( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late )
 {
-	hipLaunchKernelGGL( k_tail, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, dense_above, min_lanes, lds_words, team_below, ctr, stop_late );
+	if (qbvh) hipLaunchKernelGGL( ( k_tail<true> ), grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, dense_above, min_lanes, lds_words, team_below, ctr, stop_late );
+	else if (!qbvh) hipLaunchKernelGGL( ( k_tail<false> ), grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, dense_above, min_lanes, lds_words, team_below, ctr, stop_late );
 }
 void rtk_tail_decide( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, const uint32_t* n_in, const uint32_t* draining, uint32_t team_below, uint32_t wave_below )
 {
 	hipLaunchKernelGGL( k_tail_decide, grid, block, lds, stream, ctr, n_in, draining, team_below, wave_below );
 }
-void rtk_tail_team( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr )
+void rtk_tail_team( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
-	hipLaunchKernelGGL( k_tail_team, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
+	if (qbvh) hipLaunchKernelGGL( ( k_tail_team<true> ), grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
+	else if (!qbvh) hipLaunchKernelGGL( ( k_tail_team<false> ), grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
 }
-void rtk_tail_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr )
+void rtk_tail_wave( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
-	hipLaunchKernelGGL( k_tail_wave, grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
+	if (qbvh) hipLaunchKernelGGL( ( k_tail_wave<true> ), grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
+	else if (!qbvh) hipLaunchKernelGGL( ( k_tail_wave<false> ), grid, block, lds, stream, s, in, out, sinks, n_in, n_out, max_bounces, ctr );
 }
-void rtk_rays_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out )
+void rtk_rays_wave( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out )
 {
-	hipLaunchKernelGGL( k_rays_wave, grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
+	if (qbvh) hipLaunchKernelGGL( ( k_rays_wave<true> ), grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
+	else if (!qbvh) hipLaunchKernelGGL( ( k_rays_wave<false> ), grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
 }
 void rtk_carry_out( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState in, const uint32_t* n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap )
 {
@@ -1536,9 +1553,10 @@ void rtk_vignette( dim3 grid, dim3 block, size_t lds, hipStream_t stream, uint32
 {
 	hipLaunchKernelGGL( k_vignette, grid, block, lds, stream, px, W, H, intensity );
 }
-void rtk_trace_rays( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out )
+void rtk_trace_rays( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out )
 {
-	hipLaunchKernelGGL( k_trace_rays, grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
+	if (qbvh) hipLaunchKernelGGL( ( k_trace_rays<true> ), grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
+	else if (!qbvh) hipLaunchKernelGGL( ( k_trace_rays<false> ), grid, block, lds, stream, s, n, O3, D3, tmax, any_hit, obj_out, t_out );
 }
 void rtk_copy_hits( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState st, int n, int* obj_out, float* t_out )
 {
@@ -1552,7 +1570,8 @@ void rtk_rays_any_result( dim3 grid, dim3 block, size_t lds, hipStream_t stream,
 {
 	hipLaunchKernelGGL( k_rays_any_result, grid, block, lds, stream, Es, n, obj_out );
 }
-void rtk_whitted( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa, WFrame* frames, float4* acc )
+void rtk_whitted( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa, WFrame* frames, float4* acc )
 {
-	hipLaunchKernelGGL( k_whitted, grid, block, lds, stream, s, cam, W, H, invW, invH, mode, max_depth, aa, frames, acc );
+	if (qbvh) hipLaunchKernelGGL( ( k_whitted<true> ), grid, block, lds, stream, s, cam, W, H, invW, invH, mode, max_depth, aa, frames, acc );
+	else if (!qbvh) hipLaunchKernelGGL( ( k_whitted<false> ), grid, block, lds, stream, s, cam, W, H, invW, invH, mode, max_depth, aa, frames, acc );
 }

@@ -162,13 +162,13 @@ hipError_t rtk_scratch_address( int device, void** out );
 
 // ---- launchers (rt_kernels.hip) ----------------------------------------------------------------------------------------------
 void rtk_primary( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState st, float4* E, float4* Es, uint32_t N, CamProp cam, int W, int H, float invW, float invH, const uint32_t* seeds, int sample_begin, int sample_stride, uint32_t* wq, DevCounters* ctr );
-void rtk_trace( bool any, bool count, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr );
+void rtk_trace( bool any, bool count, bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr );
 void rtk_shade( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, uint32_t* wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr );
-void rtk_tail( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late );
+void rtk_tail( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late );
 void rtk_tail_decide( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, const uint32_t* n_in, const uint32_t* draining, uint32_t team_below, uint32_t wave_below );
-void rtk_tail_team( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr );
-void rtk_tail_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr );
-void rtk_rays_wave( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out );
+void rtk_tail_team( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr );
+void rtk_tail_wave( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, DevCounters* ctr );
+void rtk_rays_wave( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out );
 void rtk_carry_out( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState in, const uint32_t* n_in, PathState rest, uint32_t* n_rest, PathState carry, uint32_t* n_carry, uint32_t cap );
 void rtk_carry_in( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState carry, const uint32_t* n_carry, uint32_t cap, PathState st, const uint32_t* n_st, uint32_t* wq, DevCounters* ctr );
 void rtk_carry_commit( dim3 grid, dim3 block, size_t lds, hipStream_t stream, uint32_t* n_st, uint32_t* n_carry, uint32_t cap );
@@ -181,8 +181,8 @@ void rtk_finalize( dim3 grid, dim3 block, size_t lds, hipStream_t stream, const 
 void rtk_gamma( dim3 grid, dim3 block, size_t lds, hipStream_t stream, uint32_t* px, int n, const uint32_t* lut );
 void rtk_chroma( dim3 grid, dim3 block, size_t lds, hipStream_t stream, const uint32_t* src, uint32_t* dst, int W, int H, float intensity );
 void rtk_vignette( dim3 grid, dim3 block, size_t lds, hipStream_t stream, uint32_t* px, int W, int H, float intensity );
-void rtk_trace_rays( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out );
+void rtk_trace_rays( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int* obj_out, float* t_out );
 void rtk_copy_hits( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState st, int n, int* obj_out, float* t_out );
 void rtk_rays_begin( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, PathState st, ShadowQueue sq, float4* Es, uint32_t* wq, int* obj_out, float* t_out, DevCounters* ctr );
 void rtk_rays_any_result( dim3 grid, dim3 block, size_t lds, hipStream_t stream, const long long* Es, int n, int* obj_out );
-void rtk_whitted( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa, WFrame* frames, float4* acc );
+void rtk_whitted( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa, WFrame* frames, float4* acc );

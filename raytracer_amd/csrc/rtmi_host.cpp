@@ -315,21 +315,21 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 		// a draining round with few paths left belongs to k_tail_team (the device knows the live count and whether the host waits:
 		// both kernels are launched, the one whose round it is not returns at once)
 		rtk_tail_decide( dim3( 1 ), dim3( 1 ), 0, ts, ctr, &ctr->n_state[cur], c->draining_dev, team_below, wave_below );
-		rtk_tail( dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
+		rtk_tail( c->ds.qnodes != 0, dim3( blocks ), dim3( 64 * wpb ), lds_words * sizeof( uint32_t ), ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit,
 			round == 0 ? 0u : c->tail_dense, c->tail_lanes, lds_words, team_below, ctr, stop_late );
 		if (team_below > wave_below)
 		{
 			// (the draining kernels have the chip to themselves: 16 waves per CU whatever tail_waves says about tails beside a bulk)
 			const uint32_t twaves = std::max( 1u, std::min( drain_waves, std::min( upper, team_below ) ) ), tblocks = ( twaves + 3 ) / 4;
 			const size_t tlds = (size_t)c->walk_depth * 64u * sizeof( uint32_t ); // 4 waves x 16 teams, one column each
-			rtk_tail_team( dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, ctr );
+			rtk_tail_team( c->ds.qnodes != 0, dim3( tblocks ), dim3( 256 ), tlds, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, ctr );
 		}
 		if (wave_below)
 		{
 			// one wave per path, as many waves as the round can have paths (a wave that finds the pool empty leaves at once)
 			// (the rounds of 4096 bounces and more are for a handful of paths: fewer waves, cheaper to dispatch when they find nothing)
 			const uint32_t wwaves = std::max( 1u, std::min( round >= 7 ? 1024u : drain_waves, std::min( upper, wave_below ) ) ), wblocks = ( wwaves + WAVE_WG - 1 ) / WAVE_WG;
-			rtk_tail_wave( dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, ctr );
+			rtk_tail_wave( c->ds.qnodes != 0, dim3( wblocks ), dim3( 64 * WAVE_WG ), 0, ts, c->ds, st[cur], st[cur ^ 1], sinks, &ctr->n_state[cur], &ctr->n_state[cur ^ 1], limit, ctr );
 		}
 		if (c->log_bounces && drain) // diagnostics: the survivors of every draining round (synchronises)
 		{
@@ -1267,13 +1267,13 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	ScopedTimer t( c, any ? 2 : 0, s );
 	if (any)
 	{
-		if (c->count_nodes) rtk_trace( true, true, wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-		else rtk_trace( true, false, wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		if (c->count_nodes) rtk_trace( true, true, c->ds.qnodes != 0, wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		else rtk_trace( true, false, c->ds.qnodes != 0, wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 	else
 	{
-		if (c->count_nodes) rtk_trace( false, true, wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-		else rtk_trace( false, false, wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		if (c->count_nodes) rtk_trace( false, true, c->ds.qnodes != 0, wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+		else rtk_trace( false, false, c->ds.qnodes != 0, wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
 	}
 }
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
@@ -1625,7 +1625,7 @@ int rtmi_render( rtmi_ctx* c, int mode, int sample_begin, int sample_count, int 
 	}
 	{
 		ScopedTimer t( c, 3, c->stream );
-		rtk_whitted( dim3( nblocks( WH ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, mode, max_depth,
+		rtk_whitted( c->ds.qnodes != 0, dim3( nblocks( WH ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, c->cam, c->W, c->H, 1.0f / c->W, 1.0f / c->H, mode, max_depth,
 			anti_aliasing, c->frames, c->accum );
 	}
 	HIPCHK( hipGetLastError() );
@@ -1661,14 +1661,14 @@ static int launch_trace_rays( rtmi_ctx* c, int n, const float* dO, const float* 
 {
 	if (c->hook_kernel == 0)
 	{
-		rtk_trace_rays( dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+		rtk_trace_rays( c->ds.qnodes != 0, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
 		HIPCHK( hipGetLastError() );
 		return RTMI_OK;
 	}
 	if (c->hook_kernel == 2) // the end-of-render walker: one ray per wave (k_tail_wave's device code)
 	{
 		const int blocks = std::max( 1, std::min( ( n + 3 ) / 4, c->n_cus * 4 ) );
-		rtk_rays_wave( dim3( blocks ), dim3( 256 ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+		rtk_rays_wave( c->ds.qnodes != 0, dim3( blocks ), dim3( 256 ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
 		HIPCHK( hipGetLastError() );
 		return RTMI_OK;
 	}
@@ -1727,9 +1727,9 @@ int rtmi_trace_rays_noalloc( rtmi_ctx* c, int n, const float* O3, const float* D
 	// the same kernels as rtmi_trace_rays; option hook_kernel = 1 (the render path's queues) needs a render batch's buffers,
 	// which may have to be allocated, so it is served by kernel 0 here
 	if (c->hook_kernel == 2)
-		rtk_rays_wave( dim3( std::max( 1, std::min( ( n + 3 ) / 4, c->n_cus * 4 ) ) ), dim3( 256 ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+		rtk_rays_wave( c->ds.qnodes != 0, dim3( std::max( 1, std::min( ( n + 3 ) / 4, c->n_cus * 4 ) ) ), dim3( 256 ), 0, c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
 	else
-		rtk_trace_rays( dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
+		rtk_trace_rays( c->ds.qnodes != 0, dim3( nblocks( n ) ), dim3( BLOCK ), stack_bytes( c ), c->stream, c->ds, n, dO, dD, dT, any_hit, dobj, dt );
 	HIPCHK( hipGetLastError() );
 	hipError_t e1 = hipMemcpyAsync( obj_out, dobj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
 	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
