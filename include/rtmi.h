@@ -168,6 +168,18 @@ int rtmi_render( rtmi_ctx*, int mode, int sample_begin, int sample_count, int sa
 int rtmi_trace_primary( rtmi_ctx*, int32_t* prim_id_out, float* t_out );
 int rtmi_trace_rays( rtmi_ctx*, int n, const float* O3, const float* D3, const float* tmax, int any_hit, int32_t* prim_id_out, float* t_out );
 
+/* The reference's per-object methods on the device, for hosts that keep calling them one ray at a time (compat/primitive.h,
+ * compat/scene.h) -- there is no CPU implementation behind them:
+ * rtmi_intersect_primitive = Triangle / Sphere / Plane / Quad / Cube::Intersect (primitive.h:50-72, 108-127, 154-158, 284-295,
+ *   210-236) of ONE primitive handed over by value against n rays.  kind / data: 0 triangle, 9 floats pos1 pos2 pos3; 1 sphere, 4:
+ *   pos, r^2; 2 plane, 4: N, d; 3 quad, 13: rows 0..2 of invT (12 floats, row-major) + half size; 4 cube, 18: rows 0..2 of invM,
+ *   b[0], b[1].  t_in[i] = ray.t before the call; hit_out[i] != 0: the primitive was hit closer than that, t_out[i] = the new ray.t
+ *   (else t_in[i]).  Needs no scene.
+ * rtmi_hit_attributes = Scene::GetNormal (flipped against wo, scene.h:412) / GetAlbedo / GetMaterial().type (scene.h:380-478) of the
+ *   uploaded scene for n hits: global object index, intersection point I, ray direction wo. */
+int rtmi_intersect_primitive( rtmi_ctx*, int kind, const float* data, int n, const float* O3, const float* D3, const float* t_in, int32_t* hit_out, float* t_out );
+int rtmi_hit_attributes( rtmi_ctx*, int n, const int32_t* obj, const float* I3, const float* wo3, float* N3_out, float* albedo3_out, int32_t* material_out );
+
 /* No counterpart in the reference.  rtmi_trace_rays for callers that cannot allocate device memory (tight serving loops,
  * harnesses that forbid hipMalloc, a process that has handed all free HBM to other users): same arguments, same results, but
  * the rays are staged in a fixed device array that is part of the library's image (9 MB per GPU, held until the process ends)

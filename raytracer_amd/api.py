@@ -131,7 +131,7 @@ def device_lib():
                      "rtmi_set_accumulator", "rtmi_render", "rtmi_trace_primary", "rtmi_trace_rays", "rtmi_finalize", "rtmi_postprocess",
                      "rtmi_read_accumulator", "rtmi_synchronize", "rtmi_flush", "rtmi_set_profiling", "rtmi_get_stats", "rtmi_reset_stats",
                      "rtmi_use_own_stream", "rtmi_set_option", "rtmi_get_option", "rtmi_reduce_accumulator", "rtmi_trace_rays_noalloc",
-                     "rtmi_set_whitted_lights", "rtmi_memory_info"):
+                     "rtmi_set_whitted_lights", "rtmi_memory_info", "rtmi_intersect_primitive", "rtmi_hit_attributes"):
             getattr(L, name).restype = C.c_int
         L.rtmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.rtmi_destroy.argtypes = [C.c_void_p]
@@ -159,6 +159,8 @@ def device_lib():
         L.rtmi_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
         L.rtmi_reduce_accumulator.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rtmi_set_whitted_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+        L.rtmi_intersect_primitive.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.rtmi_hit_attributes.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.rtmi_memory_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _dev = L
     return _dev
@@ -536,6 +538,24 @@ class Device:
         """the two point lights of the Whitted modes (2 x float4 positions and colours, intensity) without a scene re-upload"""
         pos, color = np.ascontiguousarray(pos, np.float32).reshape(8), np.ascontiguousarray(color, np.float32).reshape(8)
         self._chk(self.L.rtmi_set_whitted_lights(self.h, _ptr(pos), _ptr(color), float(intensity)))
+
+    def intersect_primitive(self, kind, data, O, D, t_in):
+        """<Primitive>::Intersect of one primitive against n rays on the device (rtmi_intersect_primitive): (hit, t)"""
+        data = np.ascontiguousarray(data, np.float32).reshape(-1)
+        O, D, t_in = (np.ascontiguousarray(x, np.float32) for x in (O, D, t_in))
+        n = len(t_in)
+        hit, t = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        self._chk(self.L.rtmi_intersect_primitive(self.h, int(kind), _ptr(data), n, _ptr(O), _ptr(D), _ptr(t_in), _ptr(hit), _ptr(t)))
+        return hit, t
+
+    def hit_attributes(self, obj, I, wo):
+        """Scene::GetNormal / GetAlbedo / material type of n hits (rtmi_hit_attributes): (N, albedo, material)"""
+        obj = np.ascontiguousarray(obj, np.int32)
+        I, wo = np.ascontiguousarray(I, np.float32), np.ascontiguousarray(wo, np.float32)
+        n = len(obj)
+        N, alb, mat = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        self._chk(self.L.rtmi_hit_attributes(self.h, n, _ptr(obj), _ptr(I), _ptr(wo), _ptr(N), _ptr(alb), _ptr(mat)))
+        return N, alb, mat
 
     def memory_info(self):
         """(free, total) bytes of device memory"""

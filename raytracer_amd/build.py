@@ -4,6 +4,7 @@ Everything is built in-tree with explicit compiler lines (hipcc cross-compiles g
 
   raytracer_amd/librtmi.so        include/rtmi.h: csrc/rt_kernels.hip (hipcc) + csrc/rtmi_host.cpp (g++), -ffp-contract=off
   raytracer_amd/librtmi_host.so   Scene/BVH/Camera/Renderer host mirror    (g++,   -ffp-contract=off, OpenMP)
+  tests/compat/libcompat_tu.so    INTEGRATION.md 1-3 compiled against compat/ (the source-level drop-in headers), test only
   oracle/liboracle.so             CPU restatement, the parity checker      (g++,   -ffp-contract=off, OpenMP)
   oracle/_ref/libref_WxH.so       the reference itself, dev container only (oracle/ref_build/build_ref.sh)
 """
@@ -21,6 +22,9 @@ ORACLE = os.path.join(ROOT, "oracle")
 DEVICE_LIB = os.path.join(PKG, "librtmi.so")
 HOST_LIB = os.path.join(PKG, "librtmi_host.so")
 ORACLE_LIB = os.path.join(ORACLE, "liboracle.so")
+COMPAT = os.path.join(ROOT, "compat")
+COMPAT_TU = os.path.join(ROOT, "tests", "compat", "integration_tu.cpp")
+COMPAT_TU_LIB = os.path.join(ROOT, "tests", "compat", "libcompat_tu.so")
 
 
 def _newer(target, sources):
@@ -69,6 +73,23 @@ def build_host(force=False):
     return HOST_LIB
 
 
+def compat_tu_command(out=COMPAT_TU_LIB, extra=()):
+    """the compiler line a maintainer of the reference would use for renderer.cpp after the switch: the reference's include names
+    resolved by compat/, the C ABI by include/, linked against the two libraries"""
+    return ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall", "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"),
+            "-o", out, COMPAT_TU] + list(extra) + ["-L" + PKG, "-lrtmi_host", "-lrtmi", "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN/../../raytracer_amd"]
+
+
+def build_compat(force=False):
+    deps = [COMPAT_TU] + [os.path.join(COMPAT, f) for f in sorted(os.listdir(COMPAT))] + [os.path.join(HOST, f) for f in ("bvh.h", "scene.h", "rt_types.h", "qbvh.h")]
+    deps.append(os.path.join(ROOT, "include", "rtmi.h"))
+    if not force and not _newer(COMPAT_TU_LIB, deps):
+        return COMPAT_TU_LIB
+    build_host(force)
+    _run(compat_tu_command())
+    return COMPAT_TU_LIB
+
+
 def build_oracle(force=False):
     srcs = [os.path.join(ORACLE, "rt_oracle.cpp")]
     deps = srcs + [os.path.join(ROOT, "include", "rtmi.h")]
@@ -98,6 +119,7 @@ def build_all(force=False):
     build_device(force)
     build_host(force)
     build_oracle(force)
+    build_compat(force)
     build_ref()
 
 

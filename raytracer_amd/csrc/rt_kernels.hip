@@ -1302,6 +1302,43 @@ __global__ __launch_bounds__( BLOCK ) void k_rays_any_result( const long long* _
 	if (i < n && obj_out[i] == 2) obj_out[i] = Es[4 * (size_t)i] != 0 ? 0 : 1;
 }
 
+// ---- single-primitive and attribute hooks: the reference's per-object methods on the device ------------------------------------
+// Triangle / Sphere / Plane / Quad / Cube::Intersect (primitive.h:50-72, 108-127, 154-158, 284-295, 210-236) for one primitive that
+// the caller hands over by value, against n rays: the same device functions the walks use.  hit[i] = the ray was updated.
+__global__ __launch_bounds__( BLOCK ) void k_isect_one( OnePrim p, int n, const float* __restrict__ O3, const float* __restrict__ D3, const float* __restrict__ tin,
+	int* __restrict__ hit, float* __restrict__ tout )
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const f3 O = mk3( O3[3 * i], O3[3 * i + 1], O3[3 * i + 2] ), D = mk3( D3[3 * i], D3[3 * i + 1], D3[3 * i + 2] );
+	RayHit h; h.t = tin[i], h.obj = -1, h.pos = -1;
+	if (p.kind == 0)
+	{
+		// edge1 = pos2 - pos1, edge2 = pos3 - pos1 (primitive.h:55-56)
+		const float4 a = make_float4( p.d[0].x, p.d[0].y, p.d[0].z, __int_as_float( 0 ) );
+		const float4 b = make_float4( p.d[1].x - p.d[0].x, p.d[1].y - p.d[0].y, p.d[1].z - p.d[0].z, __int_as_float( 0 ) );
+		const float4 c = make_float4( p.d[2].x - p.d[0].x, p.d[2].y - p.d[0].y, p.d[2].z - p.d[0].z, 0 );
+		isect_record<false>( a, b, c, 0, O, D, h );
+	}
+	else if (p.kind == 1) isect_record<false>( make_float4( p.d[0].x, p.d[0].y, p.d[0].z, __int_as_float( 1 ) ), make_float4( p.d[0].w, 0, 0, __int_as_float( 0 ) ), make_float4( 0, 0, 0, 0 ), 0, O, D, h );
+	else if (p.kind == 2) isect_plane_nd( p.d[0], 0, O, D, h );
+	else if (p.kind == 3) { m34 M; M.r0 = p.d[0], M.r1 = p.d[1], M.r2 = p.d[2]; isect_quad_rows( M, p.d[3].x, 0, O, D, h ); }
+	else { m34 M; M.r0 = p.d[0], M.r1 = p.d[1], M.r2 = p.d[2]; isect_cube_rows( M, p.d[3], p.d[4], 0, O, D, h ); }
+	hit[i] = h.obj != -1 ? 1 : 0, tout[i] = h.t;
+}
+// Scene::GetNormal / GetAlbedo / GetMaterial (scene.h:380-478) for n hits of the uploaded scene: hit_attributes, as k_shade calls it
+__global__ __launch_bounds__( BLOCK ) void k_hit_attribs( DScene s, int n, const int* __restrict__ obj, const float* __restrict__ I3, const float* __restrict__ wo3,
+	float* __restrict__ N3, float* __restrict__ alb3, int* __restrict__ mat )
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	HitAttr a;
+	hit_attributes( s, obj[i], mk3( I3[3 * i], I3[3 * i + 1], I3[3 * i + 2] ), mk3( wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2] ), a );
+	N3[3 * i] = a.N.x, N3[3 * i + 1] = a.N.y, N3[3 * i + 2] = a.N.z;
+	alb3[3 * i] = a.albedo.x, alb3[3 * i + 1] = a.albedo.y, alb3[3 * i + 2] = a.albedo.z;
+	mat[i] = a.mat->type;
+}
+
 // ---- Whitted / debug views: Renderer::Trace without recursion (renderer.cpp:80-244) ------------------------
 // Each pending call is a frame; a GLASS frame is visited up to three times (before the reflection child, before the
 // refraction child, after both).  Frames live in a per-thread slice of a global buffer (depth <= max_depth).
@@ -1569,6 +1606,14 @@ void rtk_rays_begin( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DSce
 void rtk_rays_any_result( dim3 grid, dim3 block, size_t lds, hipStream_t stream, const long long* Es, int n, int* obj_out )
 {
 	hipLaunchKernelGGL( k_rays_any_result, grid, block, lds, stream, Es, n, obj_out );
+}
+void rtk_isect_one( dim3 grid, dim3 block, size_t lds, hipStream_t stream, OnePrim p, int n, const float* O3, const float* D3, const float* tin, int* hit, float* tout )
+{
+	hipLaunchKernelGGL( k_isect_one, grid, block, lds, stream, p, n, O3, D3, tin, hit, tout );
+}
+void rtk_hit_attribs( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const int* obj, const float* I3, const float* wo3, float* N3, float* alb3, int* mat )
+{
+	hipLaunchKernelGGL( k_hit_attribs, grid, block, lds, stream, s, n, obj, I3, wo3, N3, alb3, mat );
 }
 void rtk_whitted( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa, WFrame* frames, float4* acc )
 {

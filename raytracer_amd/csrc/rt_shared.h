@@ -154,6 +154,10 @@ struct WFrame
 	float n1, n2, ior, ratio, inc, k;
 };
 
+// one primitive handed over by value (rtmi_intersect_primitive): kind 0 triangle {p1} {p2} {p3}, 1 sphere {pos, r^2}, 2 plane {N, d},
+// 3 quad {invT rows 0..2} {size}, 4 cube {invM rows 0..2} {b0} {b1}
+struct OnePrim { int kind; int pad[3]; float4 d[5]; };
+
 #ifndef RTMI_NOALLOC_MAX_RAYS
 #define RTMI_NOALLOC_MAX_RAYS ( 1 << 18 )
 #endif
@@ -185,4 +189,6 @@ void rtk_trace_rays( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t s
 void rtk_copy_hits( dim3 grid, dim3 block, size_t lds, hipStream_t stream, PathState st, int n, int* obj_out, float* t_out );
 void rtk_rays_begin( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const float* O3, const float* D3, const float* tmax, int any_hit, PathState st, ShadowQueue sq, float4* Es, uint32_t* wq, int* obj_out, float* t_out, DevCounters* ctr );
 void rtk_rays_any_result( dim3 grid, dim3 block, size_t lds, hipStream_t stream, const long long* Es, int n, int* obj_out );
+void rtk_isect_one( dim3 grid, dim3 block, size_t lds, hipStream_t stream, OnePrim p, int n, const float* O3, const float* D3, const float* tin, int* hit, float* tout );
+void rtk_hit_attribs( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, int n, const int* obj, const float* I3, const float* wo3, float* N3, float* alb3, int* mat );
 void rtk_whitted( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, CamProp cam, int W, int H, float invW, float invH, int mode, int max_depth, int aa, WFrame* frames, float4* acc );

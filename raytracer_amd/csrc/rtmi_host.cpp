@@ -1708,6 +1708,58 @@ int rtmi_trace_rays( rtmi_ctx* c, int n, const float* O3, const float* D3, const
 	return RTMI_OK;
 }
 
+int rtmi_intersect_primitive( rtmi_ctx* c, int kind, const float* data, int n, const float* O3, const float* D3, const float* t_in, int32_t* hit_out, float* t_out )
+{
+	if (!c || kind < 0 || kind > 4 || !data || n < 0 || ( n && ( !O3 || !D3 || !t_in || !hit_out || !t_out ) )) return RTMI_ERR_INVALID;
+	if (n == 0) return RTMI_OK;
+	HIPCHK( hipSetDevice( c->device ) );
+	OnePrim p = {};
+	p.kind = kind;
+	auto f4 = [&]( int at, int k ) { float4 v = make_float4( 0, 0, 0, 0 ); memcpy( &v, data + at, (size_t)k * 4 ); return v; };
+	if (kind == 0) p.d[0] = f4( 0, 3 ), p.d[1] = f4( 3, 3 ), p.d[2] = f4( 6, 3 );
+	else if (kind == 1 || kind == 2) p.d[0] = f4( 0, 4 );
+	else if (kind == 3) p.d[0] = f4( 0, 4 ), p.d[1] = f4( 4, 4 ), p.d[2] = f4( 8, 4 ), p.d[3] = f4( 12, 1 );
+	else p.d[0] = f4( 0, 4 ), p.d[1] = f4( 4, 4 ), p.d[2] = f4( 8, 4 ), p.d[3] = f4( 12, 3 ), p.d[4] = f4( 15, 3 );
+	int r = hook_reserve( c, (size_t)n * 9 * 4 );
+	if (r) return r;
+	float* dO = (float*)c->hook_buf, *dD = dO + 3 * (size_t)n, *dT = dD + 3 * (size_t)n, *dt = dT + n;
+	int* dhit = (int*)( dt + n );
+	HIPCHK( hipMemcpyAsync( dO, O3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dD, D3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dT, t_in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream ) );
+	rtk_isect_one( dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, p, n, dO, dD, dT, dhit, dt );
+	HIPCHK( hipGetLastError() );
+	hipError_t e1 = hipMemcpyAsync( hit_out, dhit, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e2 = hipMemcpyAsync( t_out, dt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e3 = hipStreamSynchronize( c->stream );
+	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e3 );
+	return RTMI_OK;
+}
+int rtmi_hit_attributes( rtmi_ctx* c, int n, const int32_t* obj, const float* I3, const float* wo3, float* N3_out, float* albedo3_out, int32_t* material_out )
+{
+	if (!c || n < 0 || ( n && ( !obj || !I3 || !wo3 || !N3_out || !albedo3_out || !material_out ) )) return RTMI_ERR_INVALID;
+	if (!c->has_scene) return fail( c, RTMI_ERR_NO_SCENE, "rtmi_hit_attributes before rtmi_upload_scene" );
+	if (n == 0) return RTMI_OK;
+	const long long total = (long long)c->ds.n_quads + c->ds.n_spheres + c->ds.n_cubes + c->ds.n_planes + c->ds.n_tris;
+	for (int i = 0; i < n; i++) if (obj[i] < 0 || obj[i] >= total) return fail( c, RTMI_ERR_INVALID, "rtmi_hit_attributes: object index out of range" );
+	HIPCHK( hipSetDevice( c->device ) );
+	int r = hook_reserve( c, (size_t)n * 14 * 4 );
+	if (r) return r;
+	float* dI = (float*)c->hook_buf, *dW = dI + 3 * (size_t)n, *dN = dW + 3 * (size_t)n, *dA = dN + 3 * (size_t)n;
+	int* dobj = (int*)( dA + 3 * (size_t)n ), *dmat = dobj + n;
+	HIPCHK( hipMemcpyAsync( dI, I3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dW, wo3, (size_t)n * 12, hipMemcpyHostToDevice, c->stream ) );
+	HIPCHK( hipMemcpyAsync( dobj, obj, (size_t)n * 4, hipMemcpyHostToDevice, c->stream ) );
+	rtk_hit_attribs( dim3( nblocks( n ) ), dim3( BLOCK ), 0, c->stream, c->ds, n, dobj, dI, dW, dN, dA, dmat );
+	HIPCHK( hipGetLastError() );
+	hipError_t e1 = hipMemcpyAsync( N3_out, dN, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e2 = hipMemcpyAsync( albedo3_out, dA, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e4 = hipMemcpyAsync( material_out, dmat, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream );
+	hipError_t e3 = hipStreamSynchronize( c->stream );
+	HIPCHK( e1 ); HIPCHK( e2 ); HIPCHK( e4 ); HIPCHK( e3 );
+	return RTMI_OK;
+}
+
 // rtmi_trace_rays without any allocation: the rays are staged in this device's copy of `scratch` (through the address kept at
 // rtmi_create, never the array's name).  Nothing in the array has to start at zero: the copies fill the inputs of rays
 // 0 .. n-1 and the kernel writes both outputs of every one of them, so what an earlier, larger call left behind is never read.

@@ -260,3 +260,27 @@ def test_host_build_qbvh_matches_the_reference_counts(default_scene):
                 owned[child[n, s]:child[n, s] + count[n, s]] += 1
     assert (owned == 1).all()
     assert child[0, 1] == 1 and count[0, 0] == default_scene.info()["planes"]
+
+
+def test_integration_sections_compile_verbatim_against_compat(tmp_path):
+    """INTEGRATION.md 1-3 are code, not pseudo-code: the three blocks stand character for character in tests/compat/integration_tu.cpp,
+    which compiles against compat/ (the reference's header names in namespace Tmpl8) with the line a maintainer would use, and
+    the library it yields exports what tests/test_gpu_compat.py calls (no compute here: no GPU)"""
+    import re
+    import subprocess
+    from raytracer_amd import build
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    tu = open(build.COMPAT_TU).read()
+    heads = [m.start() for m in re.finditer(r"^## [123]\. ", text, re.M)]
+    assert len(heads) == 3
+    for k, at in enumerate(heads):
+        block = re.search(r"```cpp\n(.*?)```", text[at:], re.S).group(1)
+        assert len(block.splitlines()) >= 8 and block in tu, "INTEGRATION.md section %d is not in the TU verbatim" % (k + 1)
+    assert "scene.FindNearest( ray )" in tu
+    for h in ("camera.h", "primitive.h", "material.h", "bvh.h", "scene.h", "renderer.h", "precomp.h"):
+        assert "namespace Tmpl8" in open(os.path.join(ROOT, "compat", h)).read(), h
+    out = str(tmp_path / "libcompat_tu.so")
+    subprocess.check_call(build.compat_tu_command(out, extra=["-Werror"]))
+    L = C.CDLL(out)
+    for name in ("tu_init", "tu_tick", "tu_seeds", "tu_set_light", "tu_scene_queries", "tu_brute_force"):
+        assert hasattr(L, name), name

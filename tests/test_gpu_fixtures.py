@@ -178,6 +178,40 @@ def test_plane_quad_cube_unit_vectors(gold_unit, gold_small):
     d.close()
 
 
+def test_per_object_hooks_reproduce_the_reference_vectors(default_scene, gold_unit, gold_small):
+    """rtmi_intersect_primitive / rtmi_hit_attributes (what compat/primitive.h and compat/scene.h call): every one of the reference's
+    Triangle / Sphere / Plane / Quad / Cube::Intersect vectors with NO box in the way, GetNormal / GetAlbedo / material on 60 000 hits"""
+    g, d = gold_unit, api.Device(64, 64)
+    step = 40  # one call per primitive: every 40th of the 12 000 random ones, all of the adversarial head
+    for kind, key, data in ((0, "tri", g["tri_v9"]), (1, "sph", g["sph_pr"]), (2, "pl", g["pl_nd"])):
+        sel = np.r_[0:1000, 1000:12000:step]
+        hits = 0
+        for k in sel:
+            if kind == 1:
+                dat = np.r_[data[k, :3], np.float32(data[k, 3]) * np.float32(data[k, 3])].astype(np.float32)  # r2 = r * r (primitive.h:105)
+            else:
+                dat = data[k]
+            hit, t = d.intersect_primitive(kind, dat, g[key + "_O"][k:k + 1], g[key + "_D"][k:k + 1], g[key + "_tin"][k:k + 1])
+            assert bool(hit[0]) == bool(g[key + "_hit"][k] >= 0) and bits(t)[0] == bits(g[key + "_t"][k:k + 1])[0], (key, k)
+            hits += int(hit[0])
+        assert hits > 100, (key, hits)
+    quad = np.r_[gold_small["scene_quad_inv_T"][0, :12], gold_small["scene_quad_size"][0]].astype(np.float32)
+    hit, t = d.intersect_primitive(3, quad, g["quad_O"], g["quad_D"], g["quad_tin"])
+    assert np.array_equal(hit != 0, g["quad_hit"] >= 0) and np.array_equal(bits(t), bits(g["quad_t"])) and hit.sum() > 500
+    cube = np.r_[gold_small["scene_cube_inv_M"][0, :12], gold_small["scene_cube_b"][0, 0, :3], gold_small["scene_cube_b"][0, 1, :3]].astype(np.float32)
+    hit, t = d.intersect_primitive(4, cube, g["cube_O"], g["cube_D"], g["cube_tin"])
+    assert np.array_equal(hit != 0, g["cube_hit"] >= 0) and np.array_equal(bits(t), bits(g["cube_t"])) and hit.sum() > 500
+    L = api.device_lib()
+    assert L.rtmi_intersect_primitive(d.h, 5, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert L.rtmi_hit_attributes(d.h, 1, *[api._ptr(np.zeros(3, np.float32))] * 6) == -3  # no scene yet
+    d.upload(default_scene.desc)
+    gs = gold_small
+    N, alb, mat = d.hit_attributes(gs["att_obj"].astype(np.int32), gs["att_I"], gs["att_wo"])
+    assert np.array_equal(bits(N), bits(gs["att_N"])) and np.array_equal(bits(alb), bits(gs["att_albedo"])) and np.array_equal(mat, gs["att_mat"].astype(np.int32))
+    assert L.rtmi_hit_attributes(d.h, 1, api._ptr(np.array([99999], np.int32)), *[api._ptr(np.zeros(3, np.float32))] * 5) == -1
+    d.close()
+
+
 def test_config0_whitted_1280x720(default_scene, gold_720):
     """BASELINE.json configs[0] at its own size: the default scene, Whitted primary + shadow rays, 1280x720, 1 spp"""
     W, H = 1280, 720
