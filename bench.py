@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--share-of", type=int, default=1,
                     help="single process only: render the share of rank 0 of this many ranks (sample indices 0, N, 2N, ...), i.e. what ONE GPU of an "
                          "N-GPU run does between the start and the reduce; the JSON line is then a per-rank rehearsal, not a whole-node figure")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="--scaling strong: frames rendered side by side on handles of their own, so that one frame's last paths finish beside the next "
+                         "frames' bulk (raytracer_amd.distributed.FramePipeline).  0 = 4 (3: +8 % per frame, 5: same, 6: +1 %); 1 = one handle, every frame pays its end alone")
+    ap.add_argument("--slots", type=int, default=0, help="option slots of every handle (0: the library's 4; 2 per handle with frames in flight: queue memory)")
     ap.add_argument("--reduce", choices=["torch", "rtmi"], default="torch",
                     help="who sums the accumulators: torch.distributed (default) or rtmi_reduce_accumulator on an RCCL communicator of its own")
     return ap.parse_args()
@@ -98,8 +102,9 @@ def committed_pmc():
 class Leg:
     """One timed region: K steps of one view, reduce + finalize at the end (weak) or per step (strong)."""
 
-    def __init__(self, a, torch, dist, dev, acc, rank, world, use_dist, comm):
-        self.a, self.torch, self.dist, self.dev, self.acc = a, torch, dist, dev, acc
+    def __init__(self, a, torch, dist, handles, rank, world, use_dist, comm):
+        self.a, self.torch, self.dist, self.handles = a, torch, dist, handles
+        self.dev, self.stream, self.acc = handles[0]  # weak scaling, counting and the unpipelined strong loop use the first handle only
         self.rank, self.world, self.use_dist, self.comm = rank, world, use_dist, comm
         share = max(1, a.share_of)
         self.v_world, self.v_rank = (share, 0) if share > 1 else (world, rank)  # the split this process renders its part of
@@ -109,25 +114,45 @@ class Leg:
         # markers for tools/trace_union.py: two fill kernels that nothing else in the process launches bracket the timed region
         self.mark_a = torch.empty(1, dtype=torch.int16, device="cuda")  # (empty: creating them must not launch the marker kernel)
         self.mark_b = torch.empty(1, dtype=torch.int8, device="cuda")
+        self.last_reduce = None
+        self.delivered = []  # strong scaling: seconds after the start of the timed region at which each frame was in the caller's hands
 
-    def step(self, i):
+    def step(self, i, dev=None):
         from raytracer_amd import api, distributed as D
+        dev = dev or self.dev
         # step i covers the global sample indices [i*step_spp, (i+1)*step_spp); this rank renders every v_world-th one
-        D.render_split(lambda b, n, st: self.dev.render(api.PATHTRACING, b, n, st), i * self.step_spp, self.step_spp, self.v_rank, self.v_world)
+        D.render_split(lambda b, n, st: dev.render(api.PATHTRACING, b, n, st), i * self.step_spp, self.step_spp, self.v_rank, self.v_world)
 
     def barrier(self):
         if self.use_dist:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def deliver(self, n_spp):
+    def deliver(self, n_spp, handle=None, ordered=None):
         from raytracer_amd import distributed as D
-        if self.comm is not None:
-            self.dev.reduce_accumulator(self.comm, 0)  # inside the boundary: finishes the paths in flight, then one ncclReduce on the handle's stream
-        else:
-            self.dev.flush()  # the tails of the last batches run on the library's own streams: order the reduce after them
-            D.reduce_accumulator(self.acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once (no-op for one rank)
-        return self.dev.finalize(n_spp) if self.rank == 0 else None
+        import contextlib
+        dev, stream, acc = handle or self.handles[0]
+        dev.flush()  # the tails of the last batches run on the library's own streams: the reduce is ordered after them
+        with ordered or contextlib.nullcontext():  # frames in flight: the frames' collectives are issued in frame order on every rank
+            if self.comm is not None:
+                # one communicator, a stream per handle: the collectives also EXECUTE in issue order (each waits for the one before)
+                if self.last_reduce is not None:
+                    stream.wait_event(self.last_reduce)
+                dev.reduce_accumulator(self.comm, 0)  # inside the boundary: one ncclReduce on the handle's stream
+                self.last_reduce = self.torch.cuda.Event()
+                self.last_reduce.record(stream)
+            else:
+                D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once (no-op for one rank)
+        return dev.finalize(n_spp) if self.rank == 0 else None
+
+    def frame(self, k, i, ordered):
+        """one delivered frame of the strong-scaling loop on handle k: cleared accumulator, this rank's share of the frame's samples,
+        the last paths finished, the reduce, RGB8 on rank 0 -- the calls of the unpipelined loop, on a handle of the frame's own"""
+        dev, stream, acc = self.handles[k]
+        with self.torch.cuda.stream(stream):
+            acc.zero_()
+            self.step(i, dev)
+            return self.deliver(self.step_spp, self.handles[k], ordered)
 
     def count(self):
         """not timed: records per walked ray on this view, on the reference's pairs (1) and on the 4-wide nodes the timed kernels walk (2)"""
@@ -142,14 +167,19 @@ class Leg:
         return out
 
     def run(self, steps, warmup):
+        from raytracer_amd import distributed as D
         dev, acc = self.dev, self.acc
+        used = self.handles if self.strong else self.handles[:1]
         for i in range(warmup):
-            self.step(i)
-        dev.flush()  # the late paths of the warm-up batches finish (and are folded into the accumulator) before it is cleared
+            for d, _, _ in used:
+                self.step(i, d)
+        for d, _, _ in used:
+            d.flush()  # the late paths of the warm-up batches finish (and are folded into the accumulator) before it is cleared
         self.barrier()
-        acc.zero_()
-        dev.set_profiling(True, 0)
-        dev.reset_stats()
+        for d, _, a_ in used:
+            a_.zero_()
+            d.set_profiling(True, 0)
+            d.reset_stats()
         self.barrier()
         self.mark_a.fill_(1)
         self.torch.cuda.synchronize()
@@ -158,10 +188,19 @@ class Leg:
             # configs[3]: every step is a whole frame of total_spp samples -- cleared accumulator, this rank's share of the samples,
             # the last paths finished, the reduce, RGB8 on rank 0 -- so the drain and the reduce are paid per frame, as a caller
             # waiting for that frame would pay them
-            for i in range(steps):
-                acc.zero_()
-                self.step(i)
-                self.deliver(self.step_spp)
+            # as a caller waiting for that frame would pay them; with frames in flight the following frames' bulk runs meanwhile
+            if len(self.handles) > 1:
+                pipe = D.FramePipeline(len(self.handles))
+                for f in [pipe.submit(i, self.frame) for i in range(steps)]:
+                    f.result()
+                    self.delivered.append(time.perf_counter() - t0)
+                pipe.close()
+            else:
+                for i in range(steps):
+                    acc.zero_()
+                    self.step(i)
+                    self.deliver(self.step_spp)
+                    self.delivered.append(time.perf_counter() - t0)
         else:
             for i in range(steps):
                 self.step(i)
@@ -172,6 +211,14 @@ class Leg:
         self.torch.cuda.synchronize()
         st = dev.stats()
         dev.set_profiling(False, 0)
+        for d, _, _ in used[1:]:  # frames in flight: the handles' counters and timings add up
+            o = d.stats()
+            d.set_profiling(False, 0)
+            for key, v in o.items():
+                if isinstance(v, (int, float)) and not key.startswith("max_"):
+                    st[key] = st[key] + v
+                elif key.startswith("max_"):
+                    st[key] = max(st[key], v)
         torch, dist = self.torch, self.dist
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         rays = torch.tensor([st["extend_rays"] + st["shadow_rays"], st["extend_rays"], st["shadow_rays"], st["primary_samples"],
@@ -272,27 +319,38 @@ def main():
         scene, ingest = api.mesh_scene(a.tris, builder, tube=a.tube), None
     info = scene.info()
     build_s = time.time() - t0
-    dev = api.Device(W, H, local_rank, lanes=lanes)
-    dev.upload(scene.desc)
+    strong = a.scaling == "strong"
+    in_flight = (a.frames_in_flight or 4) if strong else 1
+    if in_flight > 1 and a.lanes == 0:
+        lanes = 1  # the handles' frames already run side by side
+    slots = a.slots or (2 if in_flight > 1 else 0)
     n_analytic = info["quads"] + info["spheres"] + info["cubes"] + info["planes"]
     seeds = api.seed_table(W * H)
-    dev.set_seeds(seeds)
-    # Everything below runs on ONE explicit torch stream: the library enqueues on it (rtmi_set_stream takes the stream as it
+    # Everything a handle does runs on ONE explicit torch stream: the library enqueues on it (rtmi_set_stream takes the stream as it
     # is), rtmi_flush makes it wait for the library's internal streams, and the collective -- issued while it is torch's current
     # stream -- is ordered after it by torch's own event.
-    stream = torch.cuda.Stream()
+    handles = []
+    for k in range(in_flight):
+        d = api.Device(W, H, local_rank, lanes=lanes)
+        if slots:
+            d.set_option("slots", slots)
+        d.upload(scene.desc)
+        d.set_seeds(seeds)
+        stream = torch.cuda.Stream()
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        d.set_stream(stream.cuda_stream)
+        d.set_accumulator(acc.data_ptr())
+        handles.append((d, stream, acc))
+    dev, stream, acc = handles[0]
     torch.cuda.set_stream(stream)
-    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    dev.set_stream(stream.cuda_stream)
-    dev.set_accumulator(acc.data_ptr())
     if max(1, a.share_of) > 1 and world > 1:
         raise SystemExit("--share-of is a single-process rehearsal")
     comm = rccl_communicator(dist, rank, world, local_rank) if a.reduce == "rtmi" and use_dist else None
-    leg = Leg(a, torch, dist, dev, acc, rank, world, use_dist, comm)
-    strong = leg.strong
+    leg = Leg(a, torch, dist, handles, rank, world, use_dist, comm)
 
     def view(zoom, steps, warmup):
-        dev.set_camera(api.zoom_camera(api.default_camera(W, H, scene.scale), zoom))
+        for d, _, _ in handles:
+            d.set_camera(api.zoom_camera(api.default_camera(W, H, scene.scale), zoom))
         # how much of the view is mesh: camera rays whose nearest hit is a triangle (the analytic primitives come first in the numbering)
         mesh_fraction = float((dev.trace_primary()[0] >= n_analytic).mean())
         cnt = leg.count()
@@ -329,7 +387,7 @@ def main():
                                       "per step (every step is a delivered frame)" if strong else "at the end"), "scene_scale": scene.scale,
                        "triangles": info["triangles"], "bvh_nodes": info["nodes_used"], "bvh_depth": info["max_depth"], "builder": a.builder, "scene_source": a.scene,
                        "width": W, "height": H, "spp_per_step": leg.step_spp // leg.v_world, "total_spp": a.steps * leg.step_spp, "parallelism": "sample-split x%d" % world,
-                       "reduce": a.reduce, "lanes_per_gpu": dev.get_option("lanes"), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                       "reduce": a.reduce, "lanes_per_gpu": dev.get_option("lanes"), "frames_in_flight": in_flight, "slots": dev.get_option("slots"), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "mpaths_per_s": paths / dt / 1e6, "extend_rays": ext_rays, "shadow_rays": sh_rays,
             "extend_walkers": float(st["extend_walkers"]), "shadow_walkers": float(st["shadow_walkers"]), "rays_per_path": total_rays / max(1.0, paths),
             # what the headline counts: every closest-hit and any-hit ray.  Most of them end on the room's analytic primitives inside
@@ -359,6 +417,11 @@ def main():
             bw["frac"] = bw["achieved"] / PEAK_GBS
         if mesh_view:
             out["mesh_view"] = mesh_view
+        if strong and len(leg.delivered) >= 4:
+            out["frames"] = {"in_flight": in_flight, "delivered_at_ms": [round(t * 1e3, 1) for t in leg.delivered],
+                             "steady_state_ms_per_frame": (leg.delivered[-1] - leg.delivered[in_flight - 1]) * 1e3 / (len(leg.delivered) - in_flight),
+                             "note": "ms_per_step = the whole timed region / frames (the pipeline's fill and the last frame's end included); steady state = "
+                                     "mean interval between deliveries once every handle has delivered a frame"}
         if max(1, a.share_of) > 1:
             out["rehearsal"] = "rank 0's share of a %d-rank %s-scaling run, rendered by one process: per-rank time without the reduce; not a whole-node figure" % (a.share_of, a.scaling)
         if world == 1 and not a.no_cpu_baseline:

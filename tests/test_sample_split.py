@@ -73,3 +73,45 @@ def test_two_ranks_equal_one(tmp_path):
     assert np.allclose(got, ref, rtol=2e-6, atol=1e-6)
     rmse = float(np.sqrt(np.mean((got[..., :3].astype(np.float64) - ref[..., :3]) ** 2))) / SPP
     assert rmse <= 1e-6
+
+
+def test_frame_pipeline_orders_the_collectives_and_the_results():
+    """FramePipeline: frame i runs on handle i % n, a handle's frames one after the other, the `ordered` sections strictly in frame
+    order whatever the threads' timing, results in submission order; a job that skips its section or raises still passes the turn on"""
+    import threading
+    import time
+    log, lock, running = [], threading.Lock(), {}
+
+    def job(k, i, ordered):
+        assert k == i % 3
+        with lock:
+            assert not running.get(k), "two frames on one handle at once"
+            running[k] = True
+        time.sleep(0.02 * ((7 * i) % 3))  # frames reach their collective out of order
+        if i == 4:
+            with lock:
+                running[k] = False
+            raise RuntimeError("frame 4 fails before its collective")
+        if i != 2:  # frame 2 has no collective
+            with ordered:
+                log.append(i)
+                time.sleep(0.005)
+        with lock:
+            running[k] = False
+        return i * i
+
+    pipe = D.FramePipeline(3)
+    futures = [pipe.submit(i, job) for i in range(9)]
+    with pytest.raises(ValueError):
+        pipe.submit(11, job)
+    res = []
+    for i, f in enumerate(futures):
+        if i == 4:
+            with pytest.raises(RuntimeError):
+                f.result(timeout=30)
+            res.append(None)
+        else:
+            res.append(f.result(timeout=30))
+    pipe.close()
+    assert res == [0, 1, 4, 9, None, 25, 36, 49, 64]
+    assert log == [0, 1, 3, 5, 6, 7, 8]
