@@ -126,8 +126,8 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 		primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
 		walk = begin_closest( s, O, D, h );
 		seed = sample_seed( seeds[p], sidx );
-		E[i] = make_float4( 0, 0, 0, 0 );
-		Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 ); // 4 x int64 zero
+		st_stream( &E[i], make_float4( 0, 0, 0, 0 ) );
+		st_stream( &Es[2 * (size_t)i], make_float4( 0, 0, 0, 0 ) ), st_stream( &Es[2 * (size_t)i + 1], make_float4( 0, 0, 0, 0 ) ); // 4 x int64 zero
 	}
 	const bool push[1] = { walk };
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
@@ -140,11 +140,11 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 		const uint32_t first = blockIdx.x * blockDim.x, valid = N - first < blockDim.x ? N - first : blockDim.x;
 		const uint32_t walkersBefore = idx[0] - span[0][0], nonWalkers = valid - span[0][1];
 		const uint32_t j = first + ( walk ? nonWalkers + walkersBefore : threadIdx.x - walkersBefore );
-		st.o_t[j] = make_float4( O.x, O.y, O.z, h.t );
-		st.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
-		st.T_s[j] = make_float4( 1, 1, 1, __uint_as_float( seed ) );
-		st.meta[j] = i | ( FLAG_SPECULAR << 30 );
-		if (walk) wq[idx[0]] = j;
+		st_stream( &st.o_t[j], make_float4( O.x, O.y, O.z, h.t ) );
+		st_stream( &st.d_h[j], make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) ) );
+		st_stream( &st.T_s[j], make_float4( 1, 1, 1, __uint_as_float( seed ) ) );
+		st_stream( &st.meta[j], i | ( FLAG_SPECULAR << 30 ) );
+		if (walk) st_stream( &wq[idx[0]], j );
 	}
 	if (i == 0) ctr->n_state[0] = N;
 }
@@ -543,15 +543,20 @@ __device__ __forceinline__ void shade_vertex( const DScene& s, f3 O, f3 D, float
 		{
 			T = T * ( 1.0f / p );
 			// Scene::DiffuseReflection, scene.h:517-532 (draw order x, y, z)
+			// Same bits with fewer instructions: x * 2 is exact, so fma( x, 2, -1 ) rounds what x * 2.0f - 1.0f rounds; and with a correctly
+			// rounded square root sqrtf( s ) > 1.0f exactly when s > 1 + 2^-23 (sqrt( 1 + 2^-23 ) = 1 + 2^-24 - ... rounds to 1; checked for
+			// every float in [0.25, 4)); normalize( R ) divides by the square root of the same sum
 			f3 R;
+			float len2;
 			do
 			{
-				const float rx = rng_float( rng ) * 2.0f - 1.0f;
-				const float ry = rng_float( rng ) * 2.0f - 1.0f;
-				const float rz = rng_float( rng ) * 2.0f - 1.0f;
+				const float rx = __builtin_fmaf( rng_float( rng ), 2.0f, -1.0f );
+				const float ry = __builtin_fmaf( rng_float( rng ), 2.0f, -1.0f );
+				const float rz = __builtin_fmaf( rng_float( rng ), 2.0f, -1.0f );
 				R = mk3( rx, ry, rz );
-			} while (magnitude3( R ) > 1.0f);
-			R = normalize3( R );
+				len2 = rx * rx + ry * ry + rz * rz; // magnitude( R )^2, precomp.h:848
+			} while (len2 > 1.00000011920928955078125f);
+			R = R * ( 1.0f / sqrtf( len2 ) ); // normalize( R )
 			if (dot3( N, R ) < 0) R = -R;
 			const float hemiPDF = 1.0f / ( 3.14159265358979323846264f * 2.0f );
 			v.newO = I + R * 0.001f, v.newD = R;
@@ -585,8 +590,8 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 	RayHit nh; nh.t = 1e34f, nh.obj = -1, nh.pos = -1;
 	if (i < n)
 	{
-		const float4 ot = in.o_t[i], dh = in.d_h[i], ts = in.T_s[i];
-		const uint32_t meta = in.meta[i];
+		const float4 ot = ld_stream( &in.o_t[i] ), dh = ld_stream( &in.d_h[i] ), ts = ld_stream( &in.T_s[i] );
+		const uint32_t meta = ld_stream( &in.meta[i] );
 		slot = meta & META_SLOT_MASK, flags = meta >> 30, parked = ( meta & META_SUSPENDED ) != 0;
 		age = ( meta >> META_AGE_SHIFT ) & META_AGE_LATE, late = age == META_AGE_LATE;
 		const f3 O = mk3( ot ), D = mk3( dh );
@@ -630,18 +635,18 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 		// queue has no influence on any path's arithmetic.)
 		const uint32_t before = idx[0] - span[0][0], walkersBefore = idx[1] - span[1][0], nonWalkers = span[0][1] - span[1][1];
 		const uint32_t j = span[0][0] + ( walk_next ? nonWalkers + walkersBefore : before - walkersBefore );
-		out.o_t[j] = make_float4( v.newO.x, v.newO.y, v.newO.z, nh.t );
-		out.d_h[j] = make_float4( v.newD.x, v.newD.y, v.newD.z, __int_as_float( nh.obj ) );
-		out.T_s[j] = make_float4( T.x, T.y, T.z, __uint_as_float( rng ) );
-		out.meta[j] = slot | ( age << META_AGE_SHIFT ) | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u );
-		if (walk_next) wq_out[idx[1]] = j | ( parked ? RESUME_BIT : 0u );
+		st_stream( &out.o_t[j], make_float4( v.newO.x, v.newO.y, v.newO.z, nh.t ) );
+		st_stream( &out.d_h[j], make_float4( v.newD.x, v.newD.y, v.newD.z, __int_as_float( nh.obj ) ) );
+		st_stream( &out.T_s[j], make_float4( T.x, T.y, T.z, __uint_as_float( rng ) ) );
+		st_stream( &out.meta[j], slot | ( age << META_AGE_SHIFT ) | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u ) );
+		if (walk_next) st_stream( &wq_out[idx[1]], j | ( parked ? RESUME_BIT : 0u ) );
 	}
 	if (push_shadow)
 	{
 		const uint32_t si = idx[2];
-		sq.o_t[si] = make_float4( v.shO.x, v.shO.y, v.shO.z, v.shT );
-		sq.d_s[si] = make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot | ( late ? SQ_LATE : 0u ) ) );
-		sq.c[si] = make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 );
+		st_stream( &sq.o_t[si], make_float4( v.shO.x, v.shO.y, v.shO.z, v.shT ) );
+		st_stream( &sq.d_s[si], make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot | ( late ? SQ_LATE : 0u ) ) ) );
+		st_stream( &sq.c[si], make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 	}
 	if (threadIdx.x == 0 && lds[54]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[54] );
 }
