@@ -90,6 +90,44 @@ def test_config3_4k_sample_split(scene_1m):
     d.close()
 
 
+def full_spp_split(scene, W, H, SPP, G):
+    """the config's whole sample count: one render of SPP samples against the same samples split by index over G ranks (rank r renders
+    r, r + G, ...: raytracer_amd/distributed.py) and summed as the reduce sums them.  No oracle at this size (10^9..10^10 paths): the
+    properties are that nothing is lost or dropped, that the split image is the whole image up to float summation order, and that the
+    picture is a picture"""
+    d = api.Device(W, H)
+    d.upload(scene.desc)
+    d.set_seeds(api.seed_table(W * H))
+    d.set_camera(api.default_camera(W, H, scene.scale))
+    d.reset_stats()
+    d.render(api.PATHTRACING, 0, SPP, 1)
+    whole = d.accumulator()
+    st = d.stats()
+    assert st["primary_samples"] == SPP * W * H and st["dropped_paths"] == 0
+    assert np.isfinite(whole).all() and (whole[..., :3] >= 0).all()
+    mean = whole[..., :3].mean() / SPP
+    assert 0.05 < mean < 5.0, mean
+    total = np.zeros(whole.shape, np.float64)
+    for r in range(G):
+        d.reset()
+        d.render(api.PATHTRACING, r, SPP // G, G)
+        total += d.accumulator()
+    assert d.stats()["dropped_paths"] == 0
+    # float32 accumulation of SPP terms in two different orders: each running sum rounds once per sample, at most 2^-24 of the sum
+    # each time, so the two orders differ by less than SPP * 2^-24 of the pixel's sum (half of that is still far above what is seen)
+    err = np.abs(total - whole)
+    rtol = max(1e-5, 3e-8 * SPP)
+    assert (err <= rtol * np.abs(whole) + 1e-4).all(), float((err / (np.abs(whole) + 1e-4)).max())
+    px = d.finalize(SPP // G)  # (the last rank's share, as a picture)
+    assert len(np.unique(px)) > 10000
+    d.close()
+
+
+def test_config3_full_sample_count_split_over_8_ranks(scene_1m):
+    """BASELINE.json configs[3] at its own size: 3840x2160, 256 spp, sample-split over 8 ranks (2.1 G paths, twice)"""
+    full_spp_split(scene_1m, 3840, 2160, 256, 8)
+
+
 def test_config4_10m_triangles_4k_with_postprocessing():
     W, H = 3840, 2160
     scene = api.mesh_scene(10000000, api.BINNED_SAH)
@@ -121,3 +159,8 @@ def test_config4_10m_triangles_4k_with_postprocessing():
     mism = np.argwhere(px != want)
     assert all(tuple(m) == (H // 2, W // 2) for m in mism)  # centre pixel: 0/0 in the reference
     d.close()
+
+
+def test_config4_full_sample_count_split_over_8_ranks():
+    """BASELINE.json configs[4] at its own size: ~10 M triangles, 3840x2160, 1024 spp, 8-rank sample split (8.5 G paths, twice)"""
+    full_spp_split(api.mesh_scene(10000000, api.BINNED_SAH), 3840, 2160, 1024, 8)
