@@ -114,7 +114,6 @@ class Leg:
         # markers for tools/trace_union.py: two fill kernels that nothing else in the process launches bracket the timed region
         self.mark_a = torch.empty(1, dtype=torch.int16, device="cuda")  # (empty: creating them must not launch the marker kernel)
         self.mark_b = torch.empty(1, dtype=torch.int8, device="cuda")
-        self.last_reduce = None
         self.delivered = []  # strong scaling: seconds after the start of the timed region at which each frame was in the caller's hands
 
     def step(self, i, dev=None):
@@ -135,12 +134,9 @@ class Leg:
         dev.flush()  # the tails of the last batches run on the library's own streams: the reduce is ordered after them
         with ordered or contextlib.nullcontext():  # frames in flight: the frames' collectives are issued in frame order on every rank
             if self.comm is not None:
-                # one communicator, a stream per handle: the collectives also EXECUTE in issue order (each waits for the one before)
-                if self.last_reduce is not None:
-                    stream.wait_event(self.last_reduce)
-                dev.reduce_accumulator(self.comm, 0)  # inside the boundary: one ncclReduce on the handle's stream
-                self.last_reduce = self.torch.cuda.Event()
-                self.last_reduce.record(stream)
+                # inside the boundary: one ncclReduce on the handle's stream (one communicator, a stream per handle: the library makes
+                # each reduce on a communicator execute after the one before it)
+                dev.reduce_accumulator(self.comm, 0)
             else:
                 D.reduce_accumulator(acc, dst=0)  # RCCL over xGMI: 16*W*H bytes, once (no-op for one rank)
         return dev.finalize(n_spp) if self.rank == 0 else None

@@ -216,7 +216,9 @@ int rtmi_flush( rtmi_ctx* );
  * accumulators of all ranks of `rccl_comm` (an ncclComm_t created by the caller with ncclCommInitRank / ncclCommInitAll;
  * librccl is loaded on first use) onto rank `root` with ONE ncclReduce(sum, float) over xGMI, in place, on the handle's
  * stream, after finishing the paths in flight like rtmi_flush.  root < 0: ncclAllReduce (every rank gets the sum).
- * Asynchronous like rtmi_render; rtmi_finalize on the root with frames = total samples completes the frame. */
+ * Asynchronous like rtmi_render; rtmi_finalize on the root with frames = total samples completes the frame.
+ * Several handles may share one communicator (frames in flight: raytracer_amd/host/frames.h): issue their reduces in the same order
+ * on every rank; each is made to execute after the previous one on that communicator, whichever handle's stream it is on. */
 int rtmi_reduce_accumulator( rtmi_ctx*, void* rccl_comm, int root );
 
 /* Replaces the per-frame re-read of Scene::GetLightPos / GetLightColor / intensity by Scene::DirectIllumination (scene.h:343-358,

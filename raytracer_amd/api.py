@@ -391,6 +391,21 @@ def mesh_scene_obj(n_tris_target, cache_dir, builder=BINNED_SAH, tube=0.075):
     return s, {"obj_write_s": t_write, "obj_ingest_s": t_ingest, "bvh_build_s": time.time() - t0, "obj_bytes": sum(os.path.getsize(p) for p in paths)}
 
 
+def render_frames(devices, frames, total_spp, rank=0, world=1, comm=None, finalize_spp=None):
+    """The C++ frame loop (host/frames.h through rth_render_frames): `frames` frames of total_spp samples, this rank's share, frame f
+    on devices[f % len(devices)], one host thread per handle; returns the RGB8 frames (rank 0), in order"""
+    L = host_lib()
+    W, H = devices[0].W, devices[0].H
+    hs = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    px = np.zeros((frames, H, W), np.uint32)
+    L.rth_render_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    mine = (total_spp - rank + world - 1) // world if total_spp > rank else 0
+    r = L.rth_render_frames(hs, len(devices), frames, total_spp, rank, world, comm, finalize_spp if finalize_spp is not None else mine, W, H, _ptr(px))
+    if r != 0:
+        raise RtmiError("rth_render_frames: status %d (%s)" % (r, "; ".join(d.L.rtmi_last_error(d.h).decode() for d in devices)))
+    return px
+
+
 def seed_table(n):
     out = np.zeros(n, np.uint32)
     host_lib().rth_fill_seeds(_ptr(out), n)

@@ -64,7 +64,7 @@ def build_device(force=False):
 
 def build_host(force=False):
     srcs = [os.path.join(HOST, f) for f in ("bvh.cpp", "scene.cpp", "renderer.cpp", "capi.cpp")]
-    deps = srcs + [os.path.join(HOST, f) for f in ("bvh.h", "scene.h", "renderer.h", "rt_types.h")] + [os.path.join(ROOT, "include", "rtmi.h")]
+    deps = srcs + [os.path.join(HOST, f) for f in ("bvh.h", "scene.h", "renderer.h", "rt_types.h", "qbvh.h", "frames.h")] + [os.path.join(ROOT, "include", "rtmi.h")]
     if not force and not _newer(HOST_LIB, deps):
         return HOST_LIB
     build_device(force)

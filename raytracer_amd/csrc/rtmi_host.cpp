@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <condition_variable>
 #include <dlfcn.h>
@@ -1888,8 +1889,17 @@ int rtmi_reduce_accumulator( rtmi_ctx* c, void* comm, int root )
 	{ int r = join_batches( c ); if (r) return r; } // whole samples only, and the collective is ordered after them on the handle's stream
 	const size_t count = (size_t)c->W * c->H * 4;
 	const int ncclFloat = 7, ncclSum = 0; // rccl.h:448, 466
+	// Several handles may share one communicator (frames in flight, host/frames.h): the caller issues their reduces in the same order
+	// on every rank, and here each one is also made to EXECUTE after the one before it on that communicator, whatever stream it is on
+	static std::mutex chain_m;
+	static std::unordered_map<void*, hipEvent_t> last_on_comm;
+	std::lock_guard<std::mutex> lock( chain_m );
+	hipEvent_t& last = last_on_comm[comm];
+	if (last) HIPCHK( hipStreamWaitEvent( c->stream, last, 0 ) );
+	else HIPCHK( hipEventCreateWithFlags( &last, hipEventDisableTiming ) );
 	const int e = root >= 0 ? g_rccl.reduce( c->accum, c->accum, count, ncclFloat, ncclSum, root, comm, c->stream )
 		: g_rccl.allreduce( c->accum, c->accum, count, ncclFloat, ncclSum, comm, c->stream );
+	HIPCHK( hipEventRecord( last, c->stream ) );
 	if (e != 0) return fail( c, RTMI_ERR_HIP, std::string( root >= 0 ? "ncclReduce: " : "ncclAllReduce: " ) + ( g_rccl.errstr ? g_rccl.errstr( e ) : "error" ) );
 	return RTMI_OK;
 }

@@ -1,6 +1,7 @@
 // capi.cpp -- plain-C handles over the C++ host mirror (Scene, BVH, Camera, Renderer) for the Python harness
 // (tests/, bench.py, __graft_entry__.py) via ctypes.  No arithmetic of its own.
 #include "renderer.h"
+#include "frames.h"
 #include <cstdio>
 
 using namespace rtmi;
@@ -80,6 +81,29 @@ void rth_scene_info( void* s, int* out )
 	out[5] = sc->bvh ? (int)sc->bvh->nodesUsed : 0, out[6] = sc->bvh ? sc->bvh->maxDepth : 0;
 }
 void rth_quad_T( void* s, float* T16 ) { memcpy( T16, ( (Scene*)s )->quads[0].T.cell, 64 ); }
+
+// The strong-scaling frame loop of a C++ host (frames.h): `frames` frames of total_spp samples per pixel each, this
+// rank's share of every frame (global sample indices frame * total_spp + rank + k * world) rendered on handles[frame % n_handles].
+// Per frame, the calls of the unpipelined loop: rtmi_reset_accumulator, rtmi_render, rtmi_flush; then, in frame order on every
+// rank, rtmi_reduce_accumulator( comm, 0 ) if comm != 0; then on rank 0 rtmi_finalize( finalize_spp ) into pixels_out + frame * W * H
+// (pixels_out may be 0: the frame is finished and dropped).  Returns the first error status of any frame.
+int rth_render_frames( rtmi_ctx** handles, int n_handles, int frames, int total_spp, int rank, int world, void* comm, int finalize_spp, int W, int H, uint32_t* pixels_out )
+{
+	if (!handles || n_handles < 1 || frames < 0 || total_spp < 1 || world < 1 || rank < 0 || rank >= world) return RTMI_ERR_INVALID;
+	FramePipeline pipe( n_handles );
+	const int mine = total_spp > rank ? ( total_spp - rank + world - 1 ) / world : 0;
+	for (int f = 0; f < frames; f++)
+		pipe.Submit( [&, mine]( int k, uint64_t frame ) -> int {
+			rtmi_ctx* c = handles[k];
+			int r = rtmi_reset_accumulator( c );
+			if (!r && mine > 0) r = rtmi_render( c, RTMI_PATHTRACING, (int)frame * total_spp + rank, mine, world, 5, 0 );
+			if (!r) r = rtmi_flush( c ); // the end of the frame is enqueued: it runs beside the next frames' bulk
+			if (!r && comm) { FramePipeline::Ordered turn( pipe, frame ); r = rtmi_reduce_accumulator( c, comm, 0 ); }
+			if (!r && rank == 0) r = pixels_out ? rtmi_finalize( c, pixels_out + frame * (uint64_t)W * H, finalize_spp, nullptr ) : rtmi_synchronize( c );
+			return r;
+		} );
+	return pipe.Finish();
+}
 
 void rth_fill_seeds( uint32_t* out, long long n ) { FillSeedTable( out, (size_t)n ); }
 void rth_camera_default( int w, int h, float* cam16 ) { Camera c( w, h ); memcpy( cam16, c.gpuCamProp, 64 ); }

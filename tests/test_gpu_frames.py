@@ -53,7 +53,11 @@ def test_frames_in_flight_equal_the_unpipelined_frames(default_scene):
         assert np.array_equal(got[i][0], want[i][0]), "frame %d: RGB8 differs" % i
         assert np.array_equal(bits(got[i][1]), bits(want[i][1])), "frame %d: accumulator differs" % i
     assert any(started[i + 1] < finished[i] for i in range(FRAMES - 1))  # and the frames did overlap
+    # the same loop in C++ (host/frames.h through rth_render_frames: what a C++ host links), on the same handles
+    px = api.render_frames(devs, FRAMES, TOTAL, 0, WORLD)
+    for i in range(FRAMES):
+        assert np.array_equal(px[i], want[i][0]), "C++ frame loop, frame %d" % i
     stats = [d.stats() for d in devs]
-    assert sum(s["primary_samples"] for s in stats) == FRAMES * (TOTAL // WORLD) * W * H and all(s["dropped_paths"] == 0 for s in stats)
+    assert sum(s["primary_samples"] for s in stats) == 2 * FRAMES * (TOTAL // WORLD) * W * H and all(s["dropped_paths"] == 0 for s in stats)
     for d in devs:
         d.close()

@@ -150,6 +150,24 @@ def _reduce_worker(_, out_path):
     one.render(api.PATHTRACING, 0, SPP, 1)
     want = one.accumulator()
     assert api.device_lib().rtmi_reduce_accumulator(ds[0].h, None, 0) == -1
+    # frames in flight with the reduce inside (host/frames.h through rth_render_frames): three handles of GPU 0 share rank 0's
+    # communicator, every frame's reduce is issued in frame order and chained to the one before; with one rank each frame must come
+    # out as the frame of an unpipelined loop without any reduce
+    if ndev == 1:
+        FR, T = 5, 4
+        hs = []
+        for _ in range(3):
+            h = api.Device(W, H, 0, batch=1, carry_min=0, slots=2)
+            h.upload(scene.desc)
+            h.set_seeds(seeds)
+            hs.append(h)
+        px = api.render_frames(hs, FR, T, 0, 1, comms[0])
+        for f in range(FR):
+            one.reset()
+            one.render(api.PATHTRACING, f * T, T, 1)
+            assert np.array_equal(px[f], one.finalize(T)), "frame %d" % f
+        for h in hs:
+            h.close()
     for d in ds + [one]:
         d.close()
     for k in range(ndev):
