@@ -286,6 +286,7 @@ static int ensure_batch( rtmi_ctx* c, BatchSlot& b, int S )
 // enqueued on the handle's stream after this call.
 static Sinks make_sinks( rtmi_ctx* c, const BatchSlot& b ) { Sinks k; k.E = b.E, k.Es = b.Es, k.late = c->late, k.odd = c->odd, k.WH = (uint32_t)( c->W * c->H ); return k; }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 // k_tail rounds of 32, 64, 128, ... bounces over the state set st[cur] (length ctr->n_state[cur], at most `upper`), enqueued
 // blind on `ts` (a round over an empty queue returns at once); survivors are compacted between rounds, the last round has no
 // limit.  An even number of rounds: the set that was current at the start is current, and empty, at the end.
@@ -337,7 +338,7 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 			uint32_t left = 0;
 			(void)hipStreamSynchronize( ts );
 			(void)hipMemcpy( &left, &ctr->n_state[cur ^ 1], 4, hipMemcpyDeviceToHost );
-			fprintf( stderr, "rtmi: drain round %d (%d bounces): %u paths survive\n", round, limit, left );
+			fprintf( stderr, "rtmi: drain round %d (%d bounces): %u paths survive (lane %d, host clock %.1f ms)\n", round, limit, left, c->is_child ? 1 : 0, std::fmod( now_ms(), 1e6 ) );
 		}
 		rtk_next_bounce( dim3( 1 ), dim3( 1 ), 0, ts, ctr, cur, (uint32_t*)0, round == 11 ? 1 : 0 );
 		cur ^= 1;
@@ -347,7 +348,6 @@ static int launch_tail_rounds( rtmi_ctx* c, hipStream_t ts, PathState* st, int c
 
 extern "C" { static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int stride, uint64_t ticket ); } // (defined among the entry points below)
 
-static double now_ms() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 // host time from the call that starts finishing the paths in flight to the return of the blocking call that needed them
 static void drain_closed( rtmi_ctx* c ) { if (c->drain_open) c->stats.ms_drain += now_ms() - c->drain_t0, c->stats.n_drains++, c->drain_open = false; }
 
@@ -735,6 +735,8 @@ int rtmi_set_option( rtmi_ctx* c, const char* key, long long value )
 {
 	if (!c || !key) return RTMI_ERR_INVALID;
 	HIPCHK( hipSetDevice( c->device ) );
+	// the diagnostics take effect at once -- also on the second lane -- so that the END of a render can be looked at
+	if (!strcmp( key, "log_bounces" )) { int r = apply_option( c, key, value, true ); if (!r && c->child) c->child->log_bounces = c->log_bounces; return r; }
 	{ int r = join_batches( c ); if (r) return r; } // what is in flight finishes under the settings it was started with
 	{ int r = sync_all( c ); if (r) return r; }
 	return apply_option( c, key, value, true );
@@ -1393,7 +1395,7 @@ static int render_batch( rtmi_ctx* c, BatchSlot& b, int sample_begin, int S, int
 			const int old = ( bounce - lag ) & 3;
 			HIPCHK( hipEventSynchronize( b.count_ev[old] ) );
 			upper = std::min( upper, b.host_counts[old] );
-			if (c->log_bounces && ( bounce < 64 || ( bounce & ( bounce - 1 ) ) == 0 )) fprintf( stderr, "rtmi: bounce %d starts with %u paths\n", bounce + 1 - lag, b.host_counts[old] );
+			if (c->log_bounces && ( bounce < 64 || ( bounce & ( bounce - 1 ) ) == 0 )) fprintf( stderr, "rtmi: bounce %d starts with %u paths (lane %d, host clock %.1f ms)\n", bounce + 1 - lag, b.host_counts[old], c->is_child ? 1 : 0, std::fmod( now_ms(), 1e6 ) );
 		}
 		if (upper == 0) break;
 	}
