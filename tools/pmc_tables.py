@@ -7,7 +7,7 @@ d = sys.argv[1]
 
 
 def name(n):
-    return ("k_trace<closest>" if "k_trace<false, false>" in n else "k_trace<any>" if "k_trace<true, false>" in n else "k_shade" if "k_shade" in n
+    return ("k_trace<closest>" if "k_trace<false, false" in n else "k_trace<any>" if "k_trace<true, false" in n else "k_shade" if "k_shade" in n
             else "k_tail_team" if "k_tail_team" in n else "k_tail_wave" if "k_tail_wave" in n else "k_tail" if "k_tail(" in n else "k_primary" if "k_primary" in n else None)
 
 

@@ -9,10 +9,9 @@ import csv, glob, json, os, re, sys
 
 def short(n):
     n0 = n.split("(")[0]
-    if "k_trace<false, false>" in n: return "k_trace<closest>"
-    if "k_trace<true, false>" in n: return "k_trace<any>"
-    if "k_trace<false, true>" in n: return "k_trace<closest> (counting)"
-    if "k_trace<true, true>" in n: return "k_trace<any> (counting)"
+    m = re.search(r"k_trace<(true|false), (true|false)", n)  # <ANY, COUNT, QBVH>
+    if m:
+        return "k_trace<%s>%s" % ("any" if m.group(1) == "true" else "closest", " (counting)" if m.group(2) == "true" else "")
     m = re.search(r"\b(k_\w+)", n0)
     return m.group(1) if m else n0[:48]
 

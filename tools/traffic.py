@@ -19,7 +19,7 @@ def sums(d, sub, counter):
             if r["Counter_Name"] != counter:
                 continue
             n = r["Kernel_Name"]
-            k = ("k_trace<closest>" if "k_trace<false, false>" in n else "k_trace<any>" if "k_trace<true, false>" in n else "k_shade" if "k_shade" in n else "k_primary" if "k_primary" in n
+            k = ("k_trace<closest>" if "k_trace<false, false" in n else "k_trace<any>" if "k_trace<true, false" in n else "k_shade" if "k_shade" in n else "k_primary" if "k_primary" in n
                  else "k_tail" if "k_tail" in n else "k_accumulate" if "k_accumulate" in n else None)
             if k:
                 tot[k] += float(r["Counter_Value"]); calls[k].add(r["Dispatch_Id"])
