@@ -126,8 +126,8 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 		primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
 		walk = begin_closest( s, O, D, h );
 		seed = sample_seed( seeds[p], sidx );
-		st_stream( &E[i], make_float4( 0, 0, 0, 0 ) );
-		st_stream( &Es[2 * (size_t)i], make_float4( 0, 0, 0, 0 ) ), st_stream( &Es[2 * (size_t)i + 1], make_float4( 0, 0, 0, 0 ) ); // 4 x int64 zero
+		E[i] = make_float4( 0, 0, 0, 0 );
+		Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 ); // 4 x int64 zero
 	}
 	const bool push[1] = { walk };
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
@@ -140,11 +140,11 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 		const uint32_t first = blockIdx.x * blockDim.x, valid = N - first < blockDim.x ? N - first : blockDim.x;
 		const uint32_t walkersBefore = idx[0] - span[0][0], nonWalkers = valid - span[0][1];
 		const uint32_t j = first + ( walk ? nonWalkers + walkersBefore : threadIdx.x - walkersBefore );
-		st_stream( &st.o_t[j], make_float4( O.x, O.y, O.z, h.t ) );
-		st_stream( &st.d_h[j], make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) ) );
-		st_stream( &st.T_s[j], make_float4( 1, 1, 1, __uint_as_float( seed ) ) );
-		st_stream( &st.meta[j], i | ( FLAG_SPECULAR << 30 ) );
-		if (walk) st_stream( &wq[idx[0]], j );
+		st.o_t[j] = make_float4( O.x, O.y, O.z, h.t );
+		st.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
+		st.T_s[j] = make_float4( 1, 1, 1, __uint_as_float( seed ) );
+		st.meta[j] = i | ( FLAG_SPECULAR << 30 );
+		if (walk) wq[idx[0]] = j;
 	}
 	if (i == 0) ctr->n_state[0] = N;
 }
