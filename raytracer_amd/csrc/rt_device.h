@@ -238,13 +238,16 @@ __device__ __forceinline__ void slab( float bminx, float bminy, float bminz, flo
 
 // Streams that are touched once per bounce (the path state: 3.5 GB per set at full batch size, far beyond L2 and the Infinity Cache).
 // RTMI_NT: load / store them with the non-temporal hint so that they do not displace the tree the walks beside k_shade re-read.
-#ifndef RTMI_NT
-#define RTMI_NT 1
+#ifndef RTMI_NT_LD
+#define RTMI_NT_LD 0
+#endif
+#ifndef RTMI_NT_ST
+#define RTMI_NT_ST 1
 #endif
 typedef float v4f_t __attribute__( ( ext_vector_type( 4 ) ) );
 __device__ __forceinline__ float4 ld_stream( const float4* p )
 {
-#if RTMI_NT
+#if RTMI_NT_LD
 	const v4f_t v = __builtin_nontemporal_load( (const v4f_t*)p );
 	return make_float4( v.x, v.y, v.z, v.w );
 #else
@@ -253,7 +256,7 @@ __device__ __forceinline__ float4 ld_stream( const float4* p )
 }
 __device__ __forceinline__ uint32_t ld_stream( const uint32_t* p )
 {
-#if RTMI_NT
+#if RTMI_NT_LD
 	return __builtin_nontemporal_load( p );
 #else
 	return *p;
@@ -261,7 +264,7 @@ __device__ __forceinline__ uint32_t ld_stream( const uint32_t* p )
 }
 __device__ __forceinline__ void st_stream( float4* p, float4 a )
 {
-#if RTMI_NT
+#if RTMI_NT_ST
 	v4f_t v; v.x = a.x, v.y = a.y, v.z = a.z, v.w = a.w;
 	__builtin_nontemporal_store( v, (v4f_t*)p );
 #else
@@ -270,7 +273,7 @@ __device__ __forceinline__ void st_stream( float4* p, float4 a )
 }
 __device__ __forceinline__ void st_stream( uint32_t* p, uint32_t a )
 {
-#if RTMI_NT
+#if RTMI_NT_ST
 	__builtin_nontemporal_store( a, p );
 #else
 	*p = a;
