@@ -2,6 +2,7 @@
 // (tests/, bench.py, __graft_entry__.py) via ctypes.  No arithmetic of its own.
 #include "renderer.h"
 #include "frames.h"
+#include <chrono>
 #include <cstdio>
 
 using namespace rtmi;
@@ -103,6 +104,37 @@ int rth_render_frames( rtmi_ctx** handles, int n_handles, int frames, int total_
 			return r;
 		} );
 	return pipe.Finish();
+}
+
+// frames.h without a GPU (tests/test_sample_split.py): `frames` jobs on `handles` threads that reach their collective after delays
+// out of frame order; jobs whose bit in skip_mask is set have no collective, the one numbered `fail_at` returns 7 before it.
+// order_out receives the frames in the order in which their ordered sections ran; returns Finish()'s status, or -100 - k if handle k
+// was ever given two frames at once or a frame that is not its own.
+int rth_frames_selftest( int handles, int frames, unsigned skip_mask, int fail_at, int* order_out, int* n_order )
+{
+	FramePipeline pipe( handles );
+	std::mutex m;
+	std::vector<int> busy( handles, 0 ), order;
+	int bad = 0;
+	for (int f = 0; f < frames; f++)
+		pipe.Submit( [&]( int k, uint64_t frame ) -> int {
+			{ std::lock_guard<std::mutex> lock( m ); if (busy[k]++ || (int)( frame % handles ) != k) bad = -100 - k; }
+			std::this_thread::sleep_for( std::chrono::milliseconds( 3 * ( ( 7 * frame ) % 4 ) ) );
+			int r = 0;
+			if ((int)frame == fail_at) r = 7;
+			else if (!( skip_mask >> frame & 1u ))
+			{
+				FramePipeline::Ordered turn( pipe, frame );
+				std::lock_guard<std::mutex> lock( m );
+				order.push_back( (int)frame );
+			}
+			{ std::lock_guard<std::mutex> lock( m ); busy[k]--; }
+			return r;
+		} );
+	const int status = pipe.Finish();
+	*n_order = (int)order.size();
+	for (size_t i = 0; i < order.size(); i++) order_out[i] = order[i];
+	return bad ? bad : status;
 }
 
 void rth_fill_seeds( uint32_t* out, long long n ) { FillSeedTable( out, (size_t)n ); }

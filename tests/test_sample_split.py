@@ -115,3 +115,15 @@ def test_frame_pipeline_orders_the_collectives_and_the_results():
     pipe.close()
     assert res == [0, 1, 4, 9, None, 25, 36, 49, 64]
     assert log == [0, 1, 3, 5, 6, 7, 8]
+
+
+def test_cpp_frame_pipeline_orders_the_collectives():
+    """raytracer_amd/host/frames.h (what a C++ host uses): the same properties through rth_frames_selftest, no GPU"""
+    import ctypes as C
+    from raytracer_amd import api
+    L = api.host_lib()
+    order, n = (C.c_int * 64)(), C.c_int()
+    assert L.rth_frames_selftest(3, 11, 0b100100, 7, order, C.byref(n)) == 7  # frames 2 and 5 have no collective, frame 7 fails before its own
+    assert list(order[:n.value]) == [0, 1, 3, 4, 6, 8, 9, 10]
+    assert L.rth_frames_selftest(1, 5, 0, -1, order, C.byref(n)) == 0 and list(order[:n.value]) == [0, 1, 2, 3, 4]
+    assert L.rth_frames_selftest(4, 0, 0, -1, order, C.byref(n)) == 0 and n.value == 0
