@@ -86,20 +86,24 @@ __device__ __forceinline__ void primary_ray( const CamProp& cam, float x, float 
 // The part of Scene::FindNearest that needs no BVH walk, done by the kernel that CREATES the ray while it still has it
 // in registers (every lane busy): quads[0], cubes[0], planes (scene.h:361-362, bvh.h:498-502), the reciprocal
 // direction and the root box test.  Returns true when the ray has to walk the BVH.
-__device__ __forceinline__ bool begin_closest( const DScene& s, f3 O, f3 D, RayHit& h, float t0 = 1e34f )
+// `qray` (may be null): set when the ray is one that option qbvh sends through the reference's QBVH (an infinite reciprocal direction
+// component in a scene that carries the QBVH): the queue entry is flagged, k_trace skips it, k_qbvh_fix walks it.
+__device__ __forceinline__ bool begin_closest( const DScene& s, f3 O, f3 D, RayHit& h, float t0 = 1e34f, bool* qray = nullptr )
 {
 	h.t = t0, h.obj = -1, h.pos = -1;
+	if (qray) *qray = false;
 	isect_analytic( s, O, D, h );
 	if (s.n_bvh_prims == 0) return false;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	if (inexact && s.qnodes) return true; // IntersectQBVH never tests the primitive root's own box (bvh.h:603)
+	if (inexact && s.qnodes) { if (qray) *qray = true; return true; } // IntersectQBVH never tests the primitive root's own box (bvh.h:603)
 	return ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
 }
 // Same for Scene::IsOccluded (scene.h:369-379): quad and cube with the shrinking ray.t, then the planes with early out.
-__device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tmaxRay, bool& occluded, bool& walk )
+__device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tmaxRay, bool& occluded, bool& walk, bool* qray = nullptr )
 {
 	RayHit h; h.t = tmaxRay, h.obj = -1, h.pos = -1;
+	if (qray) *qray = false;
 	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
 	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
 	if (h.obj == -1) isect_planes( s, O, D, h );
@@ -107,7 +111,8 @@ __device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tm
 	if (occluded || s.n_bvh_prims == 0) return;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 	const bool inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
-	walk = ( inexact && s.qnodes ) || ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
+	if (inexact && s.qnodes) { if (qray) *qray = true; walk = true; return; }
+	walk = ( inexact ? bvh_enter<true>( s, O, rD, h.t ) : bvh_enter<false>( s, O, rD, h.t ) ) != RT_DONE;
 }
 
 // ---- ray generation (bounce 0): camera ray, per-(pixel, sample) rng state, analytic part of FindNearest --------------
@@ -116,7 +121,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 {
 	__shared__ uint32_t lds[16 + 2];
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	bool walk = false;
+	bool walk = false, qray = false;
 	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 );
 	RayHit h; h.t = 1e34f, h.obj = -1, h.pos = -1;
 	uint32_t seed = 0;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 	{
 		const uint32_t WH = (uint32_t)( W * H ), p = i % WH, sidx = (uint32_t)sample_begin + ( i / WH ) * (uint32_t)sample_stride;
 		primary_ray( cam, (float)(int)( p % (uint32_t)W ), (float)(int)( p / (uint32_t)W ), invW, invH, O, D );
-		walk = begin_closest( s, O, D, h );
+		walk = begin_closest( s, O, D, h, 1e34f, &qray );
 		seed = sample_seed( seeds[p], sidx );
 		E[i] = make_float4( 0, 0, 0, 0 );
 		Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 ); // 4 x int64 zero
@@ -144,7 +149,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_primary( DScene s, PathState st, f
 		st.d_h[j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
 		st.T_s[j] = make_float4( 1, 1, 1, __uint_as_float( seed ) );
 		st.meta[j] = i | ( FLAG_SPECULAR << 30 );
-		if (walk) wq[idx[0]] = j;
+		if (walk) wq[idx[0]] = j | ( qray ? WQ_INEXACT : 0u );
 	}
 	if (i == 0) ctr->n_state[0] = N;
 }
@@ -230,7 +235,7 @@ __device__ __forceinline__ void add_walked( const Sinks& k, uint32_t slot, bool 
 // bounce's shadow queue; its contribution then arrives late and may meet the same path's next shadow ray in one launch,
 // which is why the contributions of walked shadow rays are summed order-independently (Es, below).
 
-template <bool ANY, bool COUNT, bool QBVH>
+template <bool ANY, bool COUNT>
 __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
@@ -295,18 +300,19 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 					{
 						has = true, sp = 0, k = 0, occluded = false, h.pos = -1, cur = s.root_ref; // the root box test passed in the creating kernel
 						uint32_t rec = 0;
+						bool qray; // option qbvh: a ray that k_qbvh_fix walks, not this kernel
 						if (ANY)
 						{
 							entry = my;
 							const float4 ot = a.sq.o_t[entry], ds = a.sq.d_s[entry];
 							O = mk3( ot ), D = mk3( ds ), h.t = ot.w, h.obj = -1, slot = __float_as_uint( ds.w );
-							resumed = ( slot & RESUME_BIT ) != 0, slot &= ~RESUME_BIT;
+							resumed = ( slot & RESUME_BIT ) != 0, slot &= ~RESUME_BIT, qray = ( slot & SQ_INEXACT ) != 0;
 							if (resumed) rec = __float_as_uint( a.sq.c[entry].w );
 						}
 						else
 						{
 							const uint32_t e = a.wq[my];
-							entry = e & ~RESUME_BIT, resumed = ( e & RESUME_BIT ) != 0;
+							entry = e & ~( RESUME_BIT | WQ_INEXACT ), resumed = ( e & RESUME_BIT ) != 0, qray = ( e & WQ_INEXACT ) != 0;
 							const float4 ot = a.st.o_t[entry], dh = a.st.d_h[entry];
 							O = mk3( ot ), D = mk3( dh ), h.t = ot.w, h.obj = __float_as_int( dh.w ); // analytic hit so far
 							if (resumed) rec = __float_as_uint( dh.w ), a.st.meta[entry] &= ~META_SUSPENDED;
@@ -321,14 +327,7 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 						rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );
 						inexact = !( fabsf( rD.x ) < INFINITY && fabsf( rD.y ) < INFINITY && fabsf( rD.z ) < INFINITY );
 						if (use_wide && !inexact && !resumed) cur = s.wide_root;
-						if (QBVH && inexact)
-						{
-							// option qbvh: this ray is one of the few on which the reference's two traversals differ; it walks the
-							// reference's QBVH here and now, whole (never parked), and retires with the next round
-							if (ANY) occluded = traverse_qbvh<true>( s, O, D, rD, h, stack, BLOCK );
-							else traverse_qbvh<false>( s, O, D, rD, h, stack, BLOCK );
-							cur = RT_DONE, inexact = false;
-						}
+						if (qray) cur = RT_DONE, inexact = false, occluded = true; // retires with the next round, untouched: no hit written, nothing added
 					}
 					chunk_next = ( chunk_end - chunk_next < (uint32_t)nIdle ) ? chunk_end : chunk_next + (uint32_t)nIdle;
 					if (chunk_next == chunk_end && chunk_end == n) exhausted = true;
@@ -444,6 +443,47 @@ __global__ __launch_bounds__( BLOCK ) void k_trace( DScene s, TraceArgs a, DevCo
 		const uint32_t nres = *a.n_rec_in < a.rec_cap ? *a.n_rec_in : a.rec_cap; // resumed rays in this launch
 		if (!ANY) atomicAdd( &ctr->extend_rays, (unsigned long long)( *a.rays_ptr - nres ) );
 		atomicAdd( ANY ? &ctr->shadow_walkers : &ctr->extend_walkers, (unsigned long long)( n - nres ) );
+	}
+}
+
+// ---- option qbvh: the rays that k_trace leaves alone ------------------------------------------------------------------------------
+// A ray with an infinite reciprocal direction component meets 0 * inf = NaN in the slab tests, and there the reference's default
+// traversal (IntersectQBVH: SSE min / max, no test of the primitive root's box, bvh.h:455-638) decides differently from its binary
+// one.  Their queue entries are flagged by the kernel that creates the ray (begin_closest / begin_any), k_trace retires them
+// untouched, and this kernel -- launched behind every k_trace of a handle whose scene carries the QBVH, over the same queue -- walks
+// the reference's own nodes for them, whole, one ray per lane.  They are few (the centre row and column of the camera rays: a zero
+// direction component needs an exact zero), so the kernel is a scan of the queue's flags; and keeping traverse_qbvh out of k_trace
+// keeps that kernel what it is without the option (inside it, the closest-hit walk was 37 % slower for rays that never take the branch).
+template <bool ANY>
+__global__ __launch_bounds__( BLOCK ) void k_qbvh_fix( DScene s, TraceArgs a )
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t* stack = lds_stack + threadIdx.x;
+	const uint32_t n = *a.count_ptr;
+	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+	{
+		RayHit h; h.obj = -1, h.pos = -1;
+		if (ANY)
+		{
+			const uint32_t slot = __float_as_uint( a.sq.d_s[i].w );
+			if (!( slot & SQ_INEXACT )) continue;
+			const float4 ot = a.sq.o_t[i], ds = a.sq.d_s[i];
+			const f3 O = mk3( ot ), D = mk3( ds );
+			h.t = ot.w;
+			if (!traverse_qbvh<true>( s, O, D, mk3( 1 / D.x, 1 / D.y, 1 / D.z ), h, stack, BLOCK ))
+				add_walked( a.sinks, slot & META_SLOT_MASK, ( slot & SQ_LATE ) != 0, a.sq.c[i] );
+		}
+		else
+		{
+			const uint32_t e = a.wq[i];
+			if (!( e & WQ_INEXACT )) continue;
+			const uint32_t entry = e & ~( RESUME_BIT | WQ_INEXACT );
+			const float4 ot = a.st.o_t[entry], dh = a.st.d_h[entry];
+			const f3 O = mk3( ot ), D = mk3( dh );
+			h.t = ot.w, h.obj = __float_as_int( dh.w ); // the analytic hit so far
+			traverse_qbvh<false>( s, O, D, mk3( 1 / D.x, 1 / D.y, 1 / D.z ), h, stack, BLOCK );
+			if (h.pos >= 0) a.st.o_t[entry].w = h.t, a.st.d_h[entry].w = __int_as_float( h.obj );
+		}
 	}
 }
 
@@ -582,7 +622,7 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 	__syncthreads();
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n = *n_in;
-	bool walk_next = false, push_shadow = false, parked = false;
+	bool walk_next = false, push_shadow = false, parked = false, qray = false, qshadow = false;
 	uint32_t slot = 0, flags = 0, rng = 0, age = 0;
 	bool late = false;
 	f3 T;
@@ -609,11 +649,11 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 			shade_vertex( s, O, D, t, obj, T, rng, flags, sinks, slot, late, v );
 			age = age < META_AGE_LATE ? age + 1 : age; // the next vertex of this path
 			// the rays created here start their life here: everything of FindNearest / IsOccluded before the BVH walk
-			if (v.push_next) walk_next = begin_closest( s, v.newO, v.newD, nh );
+			if (v.push_next) walk_next = begin_closest( s, v.newO, v.newD, nh, 1e34f, &qray );
 			if (v.shadow_any)
 			{
 				bool occluded;
-				begin_any( s, v.shO, v.shD, v.shT, occluded, push_shadow );
+				begin_any( s, v.shO, v.shD, v.shT, occluded, push_shadow, &qshadow );
 				if (!occluded && !push_shadow) add_chain( sinks, slot, late, v.contrib ); // unoccluded without a walk: E += contribution now (renderer.cpp:343)
 			}
 		}
@@ -639,13 +679,13 @@ __global__ __launch_bounds__( SBLOCK, 8 ) void k_shade( DScene s, PathState in, 
 		st_stream( &out.d_h[j], make_float4( v.newD.x, v.newD.y, v.newD.z, __int_as_float( nh.obj ) ) );
 		st_stream( &out.T_s[j], make_float4( T.x, T.y, T.z, __uint_as_float( rng ) ) );
 		st_stream( &out.meta[j], slot | ( age << META_AGE_SHIFT ) | ( flags << 30 ) | ( parked ? META_SUSPENDED : 0u ) );
-		if (walk_next) st_stream( &wq_out[idx[1]], j | ( parked ? RESUME_BIT : 0u ) );
+		if (walk_next) st_stream( &wq_out[idx[1]], j | ( parked ? RESUME_BIT : 0u ) | ( qray ? WQ_INEXACT : 0u ) );
 	}
 	if (push_shadow)
 	{
 		const uint32_t si = idx[2];
 		st_stream( &sq.o_t[si], make_float4( v.shO.x, v.shO.y, v.shO.z, v.shT ) );
-		st_stream( &sq.d_s[si], make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot | ( late ? SQ_LATE : 0u ) ) ) );
+		st_stream( &sq.d_s[si], make_float4( v.shD.x, v.shD.y, v.shD.z, __uint_as_float( slot | ( late ? SQ_LATE : 0u ) | ( qshadow ? SQ_INEXACT : 0u ) ) ) );
 		st_stream( &sq.c[si], make_float4( v.contrib.x, v.contrib.y, v.contrib.z, 0 ) );
 	}
 	if (threadIdx.x == 0 && lds[54]) atomicAdd( &ctr->shadow_rays, (unsigned long long)lds[54] );
@@ -1064,13 +1104,13 @@ __global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, 
 	__shared__ uint32_t lds[16];
 	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t nc = *n_carry < cap ? *n_carry : cap, N = *n_st; // N changes only in k_carry_commit
-	bool walk = false;
+	bool walk = false, qray = false;
 	if (j < nc)
 	{
 		const float4 ot = carry.o_t[j], dh = carry.d_h[j];
 		const f3 O = mk3( ot ), D = mk3( dh );
 		RayHit h;
-		walk = begin_closest( s, O, D, h ); // the entry's ray has not been traced yet
+		walk = begin_closest( s, O, D, h, 1e34f, &qray ); // the entry's ray has not been traced yet
 		st.o_t[N + j] = make_float4( O.x, O.y, O.z, h.t );
 		st.d_h[N + j] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
 		st.T_s[N + j] = carry.T_s[j];
@@ -1080,7 +1120,7 @@ __global__ __launch_bounds__( 512 ) void k_carry_in( DScene s, PathState carry, 
 	uint32_t* const counters[1] = { &ctr->n_walk[0] };
 	uint32_t idx[1];
 	block_append<1>( push, counters, idx, lds );
-	if (walk) wq[idx[0]] = N + j;
+	if (walk) wq[idx[0]] = ( N + j ) | ( qray ? WQ_INEXACT : 0u );
 }
 __global__ void k_carry_commit( uint32_t* n_st, uint32_t* n_carry, uint32_t cap )
 {
@@ -1265,7 +1305,7 @@ __global__ __launch_bounds__( SBLOCK ) void k_rays_begin( DScene s, int n, const
 {
 	__shared__ uint32_t lds[2 * 16];
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	bool walk = false, swalk = false;
+	bool walk = false, swalk = false, qray = false;
 	f3 O = mk3( 0, 0, 0 ), D = mk3( 0, 0, 1 );
 	float tm = 0;
 	if (i < n)
@@ -1274,14 +1314,14 @@ __global__ __launch_bounds__( SBLOCK ) void k_rays_begin( DScene s, int n, const
 		if (any_hit)
 		{
 			bool occluded;
-			begin_any( s, O, D, tm, occluded, swalk );
+			begin_any( s, O, D, tm, occluded, swalk, &qray );
 			obj_out[i] = occluded ? 1 : ( swalk ? 2 : 0 ), t_out[i] = tm;
 			Es[2 * (size_t)i] = make_float4( 0, 0, 0, 0 ), Es[2 * (size_t)i + 1] = make_float4( 0, 0, 0, 0 );
 		}
 		else
 		{
 			RayHit h;
-			walk = begin_closest( s, O, D, h, tm );
+			walk = begin_closest( s, O, D, h, tm, &qray );
 			st.o_t[i] = make_float4( O.x, O.y, O.z, h.t );
 			st.d_h[i] = make_float4( D.x, D.y, D.z, __int_as_float( h.obj ) );
 			st.T_s[i] = make_float4( 0, 0, 0, 0 );
@@ -1292,11 +1332,11 @@ __global__ __launch_bounds__( SBLOCK ) void k_rays_begin( DScene s, int n, const
 	uint32_t* const counters[2] = { &ctr->n_walk[0], &ctr->n_shadow[0] };
 	uint32_t idx[2];
 	block_append<2>( push, counters, idx, lds );
-	if (walk) wq[idx[0]] = (uint32_t)i;
+	if (walk) wq[idx[0]] = (uint32_t)i | ( qray ? WQ_INEXACT : 0u );
 	if (swalk)
 	{
 		sq.o_t[idx[1]] = make_float4( O.x, O.y, O.z, tm );
-		sq.d_s[idx[1]] = make_float4( D.x, D.y, D.z, __uint_as_float( (uint32_t)i ) );
+		sq.d_s[idx[1]] = make_float4( D.x, D.y, D.z, __uint_as_float( (uint32_t)i | ( qray ? SQ_INEXACT : 0u ) ) );
 		sq.c[idx[1]] = make_float4( 1, 0, 0, 0 );
 	}
 	if (i == 0) ctr->n_state[0] = (uint32_t)n;
@@ -1508,16 +1548,17 @@ void rtk_primary( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene 
 {
 	hipLaunchKernelGGL( k_primary, grid, block, lds, stream, s, st, E, Es, N, cam, W, H, invW, invH, seeds, sample_begin, sample_stride, wq, ctr );
 }
-void rtk_trace( bool any, bool count, bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr )
+void rtk_trace( bool any, bool count, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr )
 {
-	if (any && count && qbvh) hipLaunchKernelGGL( ( k_trace<true, true, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (any && count && !qbvh) hipLaunchKernelGGL( ( k_trace<true, true, false> ), grid, block, lds, stream, s, a, ctr );
-	else if (any && !count && qbvh) hipLaunchKernelGGL( ( k_trace<true, false, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (any && !count && !qbvh) hipLaunchKernelGGL( ( k_trace<true, false, false> ), grid, block, lds, stream, s, a, ctr );
-	else if (!any && count && qbvh) hipLaunchKernelGGL( ( k_trace<false, true, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (!any && count && !qbvh) hipLaunchKernelGGL( ( k_trace<false, true, false> ), grid, block, lds, stream, s, a, ctr );
-	else if (!any && !count && qbvh) hipLaunchKernelGGL( ( k_trace<false, false, true> ), grid, block, lds, stream, s, a, ctr );
-	else if (!any && !count && !qbvh) hipLaunchKernelGGL( ( k_trace<false, false, false> ), grid, block, lds, stream, s, a, ctr );
+	if (any && count) hipLaunchKernelGGL( ( k_trace<true, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (any && !count) hipLaunchKernelGGL( ( k_trace<true, false> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && count) hipLaunchKernelGGL( ( k_trace<false, true> ), grid, block, lds, stream, s, a, ctr );
+	else if (!any && !count) hipLaunchKernelGGL( ( k_trace<false, false> ), grid, block, lds, stream, s, a, ctr );
+}
+void rtk_qbvh_fix( bool any, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a )
+{
+	if (any) hipLaunchKernelGGL( ( k_qbvh_fix<true> ), grid, block, lds, stream, s, a );
+	else if (!any) hipLaunchKernelGGL( ( k_qbvh_fix<false> ), grid, block, lds, stream, s, a );
 }
 void rtk_shade( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, uint32_t* wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr )
 {

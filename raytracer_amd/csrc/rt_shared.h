@@ -113,6 +113,8 @@ struct DevCounters // the first 64 bytes are zeroed per render batch
 #define META_AGE_SHIFT RTMI_SLOT_BITS           // vertices behind the path, saturating at META_AGE_LATE
 #define META_AGE_LATE ( ( 1u << ( 29 - RTMI_SLOT_BITS ) ) - 1u ) // the age field fills the bits between the slot and META_SUSPENDED
 #define SQ_LATE 0x40000000u         // shadow queue slot word: the shadow ray left a late vertex
+#define SQ_INEXACT 0x10000000u      // shadow queue slot word / walk queue entry (WQ_INEXACT): option qbvh, a ray with an infinite reciprocal
+#define WQ_INEXACT 0x40000000u      // direction component -- k_trace leaves it alone, k_qbvh_fix walks the reference's QBVH for it
 #define META_SUSPENDED 0x20000000u // the closest-hit walk of this path was parked (k_trace); k_shade passes it through
 #define RESUME_BIT 0x80000000u     // walk queue entry / shadow slot field: resume from a suspend record
 #define REC_HEADER 6               // suspend record: cur, sp, k, h.obj, h.pos, -, then the stack
@@ -166,7 +168,8 @@ hipError_t rtk_scratch_address( int device, void** out );
 
 // ---- launchers (rt_kernels.hip) ----------------------------------------------------------------------------------------------
 void rtk_primary( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState st, float4* E, float4* Es, uint32_t N, CamProp cam, int W, int H, float invW, float invH, const uint32_t* seeds, int sample_begin, int sample_stride, uint32_t* wq, DevCounters* ctr );
-void rtk_trace( bool any, bool count, bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr );
+void rtk_trace( bool any, bool count, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a, DevCounters* ctr );
+void rtk_qbvh_fix( bool any, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, TraceArgs a );
 void rtk_shade( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, ShadowQueue sq, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, uint32_t* wq_out, uint32_t* n_walk_out, uint32_t* n_shadow, DevCounters* ctr );
 void rtk_tail( bool qbvh, dim3 grid, dim3 block, size_t lds, hipStream_t stream, DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* n_in, uint32_t* n_out, int max_bounces, uint32_t dense_above, int min_lanes, uint32_t lds_words, uint32_t team_below, DevCounters* ctr, int stop_late );
 void rtk_tail_decide( dim3 grid, dim3 block, size_t lds, hipStream_t stream, DevCounters* ctr, const uint32_t* n_in, const uint32_t* draining, uint32_t team_below, uint32_t wave_below );

@@ -1268,16 +1268,9 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	a.n_shadow_out = &ctr->n_shadow[set ^ 1];
 	a.rec_cap = b.rec_cap, a.rec_stride = b.rec_stride, a.refill = c->refill, a.budget = budget, a.count_wide = c->count_nodes == 2;
 	ScopedTimer t( c, any ? 2 : 0, s );
-	if (any)
-	{
-		if (c->count_nodes) rtk_trace( true, true, c->ds.qnodes != 0, wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-		else rtk_trace( true, false, c->ds.qnodes != 0, wgrid( c, true, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-	}
-	else
-	{
-		if (c->count_nodes) rtk_trace( false, true, c->ds.qnodes != 0, wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-		else rtk_trace( false, false, c->ds.qnodes != 0, wgrid( c, false, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-	}
+	rtk_trace( any, c->count_nodes != 0, wgrid( c, any, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
+	// option qbvh: the few rays that follow the reference's QBVH (flagged queue entries, which k_trace retires untouched)
+	if (c->ds.qnodes) rtk_qbvh_fix( any, dim3( (unsigned)std::min<size_t>( (size_t)c->n_cus * 4, ( (size_t)upper + BLOCK - 1 ) / BLOCK + 1 ) ), dim3( BLOCK ), lds, s, c->ds, a );
 }
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
 {
