@@ -344,8 +344,14 @@ __device__ __forceinline__ bool traverse( const DScene& s, f3 O, f3 D, f3 rD, Ra
 // node << 8 | prevOccluded << 7 | box mask << 3 | next slot).  Returns true iff ANY and occluded.
 __device__ __forceinline__ float sse_min( float a, float b ) { return a < b ? a : b; }
 __device__ __forceinline__ float sse_max( float a, float b ) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t qbvh_boxes( const DScene& s, uint32_t node, f3 O, f3 rD, float ray_t )
+// `prune`: a child is also left out when the ray provably enters its box beyond `prune` -- the entry distance over the axes whose
+// reciprocal is finite is a lower bound of every hit inside the box, NaN-free -- which the caller sets a little beyond the best hit so
+// far (closest hit) or to +inf (any hit).  IntersectQBVH never refreshes ray_t and so visits every box on the ray's line to the far
+// wall, thousands of nodes for a ray through a dense mesh; a box entered beyond the best hit cannot hold a primitive that passes
+// `t < ray.t`, so the outcome is the same, hit for hit and tie for tie.
+__device__ __forceinline__ uint32_t qbvh_boxes( const DScene& s, uint32_t node, f3 O, f3 rD, float ray_t, float prune )
 {
+	const bool fx = fabsf( rD.x ) < INFINITY, fy = fabsf( rD.y ) < INFINITY, fz = fabsf( rD.z ) < INFINITY;
 	const float4* q = s.qnodes + 8 * (size_t)node;
 	const float4 nx = q[0], xx = q[1], ny = q[2], xy = q[3], nz = q[4], xz = q[5];
 	const float bnx[4] = { nx.x, nx.y, nx.z, nx.w }, bxx[4] = { xx.x, xx.y, xx.z, xx.w }, bny[4] = { ny.x, ny.y, ny.z, ny.w };
@@ -360,7 +366,11 @@ __device__ __forceinline__ uint32_t qbvh_boxes( const DScene& s, uint32_t node, 
 		tmin = sse_max( tmin, sse_min( ty1, ty2 ) ), tmax = sse_min( tmax, sse_max( ty1, ty2 ) );
 		const float tz1 = ( bnz[l] - O.z ) * rD.z, tz2 = ( bxz[l] - O.z ) * rD.z;
 		tmin = sse_max( tmin, sse_min( tz1, tz2 ) ), tmax = sse_min( tmax, sse_max( tz1, tz2 ) );
-		if (tmax >= tmin && tmin < ray_t && tmax > 0) mask |= 1u << l;
+		float enter = -INFINITY;
+		if (fx) enter = fmaxf( enter, fminf( tx1, tx2 ) );
+		if (fy) enter = fmaxf( enter, fminf( ty1, ty2 ) );
+		if (fz) enter = fmaxf( enter, fminf( tz1, tz2 ) );
+		if (tmax >= tmin && tmin < ray_t && tmax > 0 && !( enter > prune )) mask |= 1u << l;
 	}
 	return mask;
 }
@@ -368,7 +378,9 @@ template <bool ANY>
 __device__ __forceinline__ bool traverse_qbvh( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride )
 {
 	const float ray_t = h.t;
-	uint32_t node = s.qroot, slot = 0, mask = qbvh_boxes( s, node, O, rD, ray_t );
+	// (0.1 % and 0.001 beyond the best hit: a hit's t and its box's entry distance are each within a few ulp of the same exact number)
+	#define QBVH_PRUNE ( ANY ? INFINITY : h.t * 1.001f + 0.001f )
+	uint32_t node = s.qroot, slot = 0, mask = qbvh_boxes( s, node, O, rD, ray_t, QBVH_PRUNE );
 	bool prev = false;   // ANY: prevOccluded of the current call (bvh.h:724)
 	bool anyHit = false; // ANY: ray.objIdx != -1
 	int sp = 0, best = -1;
@@ -396,7 +408,7 @@ __device__ __forceinline__ bool traverse_qbvh( const DScene& s, f3 O, f3 D, f3 r
 			{
 				stack[sp * stride] = node << 8 | ( prev ? 128u : 0u ) | mask << 3 | ( slot + 1 );
 				sp++;
-				node = (uint32_t)c, slot = 0, prev = false, mask = qbvh_boxes( s, node, O, rD, ray_t );
+				node = (uint32_t)c, slot = 0, prev = false, mask = qbvh_boxes( s, node, O, rD, ray_t, QBVH_PRUNE );
 			}
 		}
 		else leave = true, result = prev; // bvh.h:757
@@ -409,6 +421,7 @@ __device__ __forceinline__ bool traverse_qbvh( const DScene& s, f3 O, f3 D, f3 r
 		}
 	}
 }
+#undef QBVH_PRUNE
 // a ray with an infinite reciprocal direction component: the reference's default traversal where the scene carries it (option
 // qbvh), else its binary traversal with the scalar slab test's NaN propagation.  QBVH is a template parameter of every kernel
 // that walks rays: the instantiations a handle without the option launches carry none of traverse_qbvh's code or registers

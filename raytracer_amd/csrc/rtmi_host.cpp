@@ -47,6 +47,7 @@ struct BatchSlot
 	hipEvent_t count_ev[4] = { 0, 0, 0, 0 };
 	hipStream_t tail_stream = 0;
 	hipEvent_t ev_shade = 0, ev_any = 0; // side stream hand-shake (render_batch)
+	hipEvent_t ev_q0 = 0, ev_q1 = 0;     // option qbvh: k_qbvh_fix of a closest-hit walk runs on the side stream beside it (launch_trace)
 	PathState left = {};        // late paths that outlived the first round of this batch's k_tail: they join the next batch that uses the slot
 	uint32_t* n_left = 0;
 	hipEvent_t bulk_done = 0, acc_done = 0;
@@ -464,6 +465,7 @@ static int init_slot( rtmi_ctx* c, BatchSlot& b )
 	for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags( &b.count_ev[i], hipEventDisableTiming ) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags( &b.bulk_done, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.acc_done, hipEventDisableTiming ) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags( &b.ev_shade, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.ev_any, hipEventDisableTiming ) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags( &b.ev_q0, hipEventDisableTiming ) == hipSuccess && hipEventCreateWithFlags( &b.ev_q1, hipEventDisableTiming ) == hipSuccess;
 	if (!ok) return RTMI_ERR_HIP;
 	(void)hipMemset( b.ctr, 0, sizeof( DevCounters ) );
 	if (dev_alloc( c, &b.n_left, 1 )) return RTMI_ERR_NOMEM;
@@ -721,6 +723,8 @@ int rtmi_destroy( rtmi_ctx* c )
 		if (b.acc_done) (void)hipEventDestroy( b.acc_done );
 		if (b.ev_shade) (void)hipEventDestroy( b.ev_shade );
 		if (b.ev_any) (void)hipEventDestroy( b.ev_any );
+		if (b.ev_q0) (void)hipEventDestroy( b.ev_q0 );
+		if (b.ev_q1) (void)hipEventDestroy( b.ev_q1 );
 		if (b.tail_stream) (void)hipStreamDestroy( b.tail_stream );
 	}
 	if (c->draining) (void)hipHostFree( c->draining );
@@ -1268,9 +1272,21 @@ static void launch_trace( rtmi_ctx* c, BatchSlot& b, bool any, int set, uint32_t
 	a.n_shadow_out = &ctr->n_shadow[set ^ 1];
 	a.rec_cap = b.rec_cap, a.rec_stride = b.rec_stride, a.refill = c->refill, a.budget = budget, a.count_wide = c->count_nodes == 2;
 	ScopedTimer t( c, any ? 2 : 0, s );
+	// option qbvh: the few rays that follow the reference's QBVH (flagged queue entries, which k_trace retires untouched) are walked
+	// by k_qbvh_fix over the same queue.  They are few but long (the camera rays' centre row: thousands of nodes each under the NaN
+	// semantics, 3.7 ms for a batch's first bounce), so beside a closest-hit walk the kernel runs on the side stream, not behind it.
+	const dim3 qgrid( (unsigned)std::min<size_t>( (size_t)c->n_cus * 4, ( (size_t)upper + BLOCK - 1 ) / BLOCK + 1 ) );
+	const bool beside = c->ds.qnodes && !any && c->overlap_on && c->side && s != c->side && b.ev_q0;
+	if (beside)
+	{
+		(void)hipEventRecord( b.ev_q0, s );
+		(void)hipStreamWaitEvent( c->side, b.ev_q0, 0 );
+		rtk_qbvh_fix( false, qgrid, dim3( BLOCK ), lds, c->side, c->ds, a );
+		(void)hipEventRecord( b.ev_q1, c->side );
+	}
 	rtk_trace( any, c->count_nodes != 0, wgrid( c, any, upper ), dim3( BLOCK ), lds, s, c->ds, a, ctr );
-	// option qbvh: the few rays that follow the reference's QBVH (flagged queue entries, which k_trace retires untouched)
-	if (c->ds.qnodes) rtk_qbvh_fix( any, dim3( (unsigned)std::min<size_t>( (size_t)c->n_cus * 4, ( (size_t)upper + BLOCK - 1 ) / BLOCK + 1 ) ), dim3( BLOCK ), lds, s, c->ds, a );
+	if (beside) (void)hipStreamWaitEvent( s, b.ev_q1, 0 );
+	else if (c->ds.qnodes) rtk_qbvh_fix( any, qgrid, dim3( BLOCK ), lds, s, c->ds, a );
 }
 static void launch_primary( rtmi_ctx* c, BatchSlot& b, uint32_t N, int sample_begin, int stride )
 {
