@@ -638,3 +638,37 @@ def test_obj_with_mtl_materials_renders_like_the_oracle(tmp_path):
     d.render(api.PATHTRACING, 0, 4, 1)
     assert rmse(d.accumulator()[..., :3], orc.sample(W, H, cam, seeds, 0, 4)[..., :3]) <= 4e-5
     d.close()
+
+
+@pytest.mark.parametrize("hook_kernel", [0, 1])
+def test_reference_default_traversal_through_a_dense_mesh(hook_kernel):
+    """Option qbvh on a 100 k-triangle scene: rays with zero direction components (the ones that walk the reference's own QBVH,
+    where the device leaves out boxes entered beyond the best hit so far) through the knots, axis-aligned and in the coordinate planes,
+    from inside the room and from grid-aligned origins -- against the oracle's QBVH restatement, which visits every box as the
+    reference does.  Closest and any hit; the plain hook walk and the render path's k_trace + k_qbvh_fix."""
+    scene = api.mesh_scene(100000, api.REFERENCE_SAH if hook_kernel == 0 else api.BINNED_SAH)
+    k = scene.scale
+    orc = Oracle(scene.desc)
+    assert orc.set_qbvh(True)
+    d = api.Device(64, 64, qbvh=1, hook_kernel=hook_kernel)
+    d.upload(scene.desc)
+    rng = np.random.default_rng(5 + hook_kernel)
+    n = 24000
+    O = np.stack([rng.uniform(-2.9, 2.9, n), rng.uniform(-0.95, 1.95, n), rng.uniform(-2.9, 3.9, n)], 1).astype(np.float32) * np.float32(k)
+    O[:4000, 1] = rng.uniform(-0.3, 0.3, 4000).astype(np.float32) * np.float32(k)  # through the knots' height
+    O[4000:6000] = np.round(O[4000:6000])
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D[:8000, 1] = 0      # in horizontal planes (the camera's centre row is such a ray)
+    D[8000:12000, 0] = 0
+    D[12000:16000, 2] = 0
+    D[16000:18000, :2] = 0
+    D[18000:20000, 1:] = 0
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    tmax = np.full(n, 1e34, np.float32)
+    c_obj, c_t = orc.find_nearest(O, D, tmax)
+    g_obj, g_t = d.trace_rays(O, D, tmax)
+    assert (c_obj >= 7).mean() > 0.05  # the mesh is hit often enough to matter
+    assert np.array_equal(g_obj, c_obj) and np.array_equal(bits(g_t), bits(c_t))
+    ts = (np.minimum(c_t, 50 * k) * rng.uniform(0.2, 1.5, n)).astype(np.float32)
+    assert np.array_equal(d.trace_rays(O, D, ts, any_hit=True)[0], orc.is_occluded(O, D, ts))
+    d.close()
