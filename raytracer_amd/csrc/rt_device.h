@@ -423,9 +423,9 @@ __device__ __forceinline__ bool traverse_qbvh( const DScene& s, f3 O, f3 D, f3 r
 }
 #undef QBVH_PRUNE
 // a ray with an infinite reciprocal direction component: the reference's default traversal where the scene carries it (option
-// qbvh), else its binary traversal with the scalar slab test's NaN propagation.  QBVH is a template parameter of every kernel
-// that walks rays: the instantiations a handle without the option launches carry none of traverse_qbvh's code or registers
-// (inlined into k_trace it cost 12 VGPRs and 4 % of the bench).
+// qbvh), else its binary traversal with the scalar slab test's NaN propagation.  QBVH is a template parameter of the kernels in
+// which one lane or wave runs a whole path or ray (tails, hooks, Whitted): the instantiations a handle without the option launches
+// carry none of traverse_qbvh's code or registers.  k_trace has no such parameter: there these rays are left to k_qbvh_fix.
 template <bool ANY, bool QBVH>
 __device__ __forceinline__ bool walk_inexact( const DScene& s, f3 O, f3 D, f3 rD, RayHit& h, uint32_t* stack, const int stride )
 {
