@@ -837,7 +837,7 @@ __global__ void k_tail_decide( DevCounters* ctr, const uint32_t* __restrict__ n_
 // random stream) is computed identically by the four lanes, and lane 0 alone writes.  Same visiting order, same
 // arithmetic, same results as k_tail, which stays in charge of every round that is not a draining round with few paths.
 template <bool QBVH>
-__global__ __launch_bounds__( 256 ) void k_tail_team( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
+__global__ __launch_bounds__( 256, 4 ) void k_tail_team( DScene s, PathState in, PathState out, Sinks sinks, const uint32_t* __restrict__ n_in,
 	uint32_t* n_out, int max_bounces, DevCounters* ctr )
 {
 	extern __shared__ uint32_t lds_stack[];
