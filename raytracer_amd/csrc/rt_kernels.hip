@@ -104,9 +104,9 @@ __device__ __forceinline__ void begin_any( const DScene& s, f3 O, f3 D, float tm
 {
 	RayHit h; h.t = tmaxRay, h.obj = -1, h.pos = -1;
 	if (qray) *qray = false;
-	if (s.n_quads > 0) isect_quad( s, 0, O, D, h );
+	if (s.n_quads > 0) isect_quad<true>( s, 0, O, D, h ); // (<true>: quotient_reaches, rt_device.h -- the divisions that cannot matter are left out)
 	if (s.n_cubes > 0) isect_cube( s, 0, O, D, h );
-	if (h.obj == -1) isect_planes( s, O, D, h );
+	if (h.obj == -1) isect_planes<true>( s, O, D, h );
 	occluded = h.obj != -1, walk = false;
 	if (occluded || s.n_bvh_prims == 0) return;
 	const f3 rD = mk3( 1 / D.x, 1 / D.y, 1 / D.z );

@@ -289,6 +289,23 @@ def test_plane_pairs_equal_the_plane_loop(default_scene, hook_kernel):
         res.append((obj, t, occ))
         d.close()
     assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(res[0], res[1]))
+    # shadow rays that end AT the surface they would hit, and one or a few ulp before and beyond it: the any-hit tests of the kernel that
+    # creates a shadow ray leave out divisions whose quotient cannot be below the ray's end (rt_device.h: quotient_reaches) -- the
+    # boundary between "occluded" and "not" must stay where the division puts it.  Planes, the light quad, the cube, through the
+    # render path's begin_any (hook kernel 1) and the plain walk (0)
+    inside = ~outside & (c_obj >= 0) & (c_t < 100)
+    Oi, Di, ti = O[inside][:60000], D[inside][:60000], c_t[inside][:60000]
+    d = api.Device(64, 64, hook_kernel=hook_kernel)
+    d.upload(default_scene.desc)
+    for steps in (0, 1, -1, 2, -2, 5, -5, 64, -64):
+        ends = ti.copy()
+        for _ in range(abs(steps)):
+            ends = np.nextafter(ends, np.float32(np.inf if steps > 0 else 0))
+        want = orc.is_occluded(Oi, Di, ends)
+        assert np.array_equal(d.trace_rays(Oi, Di, ends, any_hit=True)[0], want), steps
+        if steps in (0, 1):
+            assert (0.0 if steps == 0 else 0.9) <= want.mean() <= (0.1 if steps == 0 else 1.0)  # `t < ray.t` is strict: a ray that ends at the hit is free
+    d.close()
 
 
 def qbvh_oracle(desc):
