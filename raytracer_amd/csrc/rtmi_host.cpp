@@ -140,6 +140,7 @@ struct rtmi_ctx
 	int batch_opt = 0;          // option batch: samples per render batch (0 = as many as 2^RTMI_SLOT_BITS paths allow)
 	int fit_samples = 0;        // > 0: the largest batch whose queues were found to fit in device memory (rtmi_render)
 	int blocks_per_cu_opt = 0;  // resident walk blocks per CU (0 = min(4, what the LDS stack allows); 3 beside a second lane, set_lanes)
+	int any_blocks_per_cu = 0;  // ... of the any-hit walk (0 = the same; 2 beside a second lane: see the option lanes)
 	bool tail_paths_set = false;
 	bool check_launches = false; // option check_launches: synchronise and check after every bounce (localises a fault; slow)
 	int hook_kernel = 0;        // option hook_kernel: rtmi_trace_rays runs 0 = k_trace_rays (one ray per lane over the reference's pairs),
@@ -518,7 +519,11 @@ static int apply_option( rtmi_ctx* c, const char* key, long long v, bool live )
 		c->lanes = (int)v;
 		// beside another lane's kernels 3 resident walk blocks per CU and 8 tail waves per CU do better than 4 and 16
 		// (20 bench steps: 10 358 -> 10 623 Mrays/s; alone, 4 and 16 are the optimum)
-		c->blocks_per_cu_opt = c->lanes == 2 ? 3 : 0, c->tail_waves = c->lanes == 2 ? 8 : 16;
+		// and the shadow walk 2: it runs beside this lane's next closest-hit walk AND the other lane's kernels, and the fewer of its waves sit
+		// on a SIMD the sooner the closest-hit walk and k_shade, which the bounce waits for, get theirs (closest / any blocks per CU, 20 steps:
+		// 3 / 3 12 046 Mrays/s, 3 / 2 12 309, 2 / 2 12 089, 2 / 3 11 893, 4 / 2 11 983, 3 / 1 11 984; 64 steps: 13 152 -> 13 535; one lane
+		// stays at 4 / 4: 10 971 against 10 860 with 4 / 3 and 10 484 with 4 / 2)
+		c->blocks_per_cu_opt = c->lanes == 2 ? 3 : 0, c->any_blocks_per_cu = c->lanes == 2 ? 2 : 0, c->tail_waves = c->lanes == 2 ? 8 : 16;
 		if (live) { set_max_blocks( c ); int r = set_lanes( c ); if (r) return r; }
 	}
 	else if (is( "slots" ))
@@ -582,7 +587,7 @@ static int sync_child( rtmi_ctx* c )
 	k->cam = c->cam, k->seeds = c->seeds, k->accum = c->accum, k->late = c->late, k->odd = c->odd;
 	k->carry_on = c->carry_on, k->carry_min = c->carry_min, k->small_paths = c->small_paths, k->count_lag = c->count_lag, k->carry_bounce = c->carry_bounce, k->tail_paths = c->tail_paths;
 	k->tail_lanes = c->tail_lanes, k->sblock = c->sblock, k->tail_waves = c->tail_waves, k->tail_block = c->tail_block, k->tail_dense = c->tail_dense;
-	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->check_launches = c->check_launches;
+	k->log_bounces = c->log_bounces, k->budget = c->budget, k->batch_opt = c->batch_opt, k->blocks_per_cu_opt = c->blocks_per_cu_opt, k->any_blocks_per_cu = c->any_blocks_per_cu, k->check_launches = c->check_launches;
 	k->tail_team = c->tail_team, k->team_below = c->team_below, k->tail_wave = c->tail_wave, k->wave_below = c->wave_below;
 	k->prof_events = c->prof_events, k->count_nodes = c->count_nodes, k->prof_base = c->prof_base, k->last_round_bounces = c->last_round_bounces, k->preview_reads = c->preview_reads;
 	int r = RTMI_OK;
@@ -1254,7 +1259,8 @@ static inline dim3 wgrid( rtmi_ctx* c, bool any, uint32_t upper )
 {
 	const uint32_t* lim = any ? c->grid_any : c->grid_closest; // path counts below which a launch gets 3, then 2 blocks per CU
 	const int per_cu = upper < lim[1] ? 2 : upper < lim[0] ? 3 : 4;
-	const int blocks = std::min( c->max_blocks, c->n_cus * per_cu );
+	int blocks = std::min( c->max_blocks, c->n_cus * per_cu );
+	if (any && c->any_blocks_per_cu > 0) blocks = std::min( blocks, c->n_cus * c->any_blocks_per_cu );
 	return dim3( (unsigned)std::max( 1, std::min( nblocks( upper ), blocks ) ) );
 }
 
